@@ -1,0 +1,204 @@
+/*
+ * mts.h -- C ABI of the MI355X-native sentence-boundary tagger hot path (libmts_hip.so).
+ *
+ * Drop-in boundary: the reference (Ighina/MultimodalTopicSegmentation) is pure Python; its "operator
+ * interface" for this path is the duck-type between models/lightning_model.py::TextSegmenter and the
+ * tagger object it owns (models/CRF.py: .loss(xs, lengths, tags) -> scalar, .forward(xs, lengths) ->
+ * (scores, tags), models/CRF.py:274-369, :371-479, :508-610) plus the batch dict of
+ * EncoderDataset.py:91-152.  There is no FFI in the reference, so this header defines the C entry
+ * points a ctypes binding on the reference side would call (INTEGRATION.md shows that binding).  Each
+ * entry point names the reference code it replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the name ends in _host; no ownership is transferred, the
+ *    caller allocates outputs and workspaces (through torch, hipMalloc, ...);
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
+ *  - row-major tensors, leading dimensions in ELEMENTS;
+ *  - return value: 0 = MTS_OK, otherwise an mts_status; mts_last_error() gives a message (thread local);
+ *  - "act dtype" = the arithmetic/storage type of activations: MTS_F32 (parity mode, fp32 everywhere) or
+ *    MTS_BF16 (bf16 storage + MFMA, fp32 accumulate/statistics).  Parameters and gradients are always fp32.
+ */
+#ifndef MTS_H
+#define MTS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  MTS_OK = 0,
+  MTS_ERR_INVALID = 1,      /* bad argument (shape, alignment, enum) */
+  MTS_ERR_UNSUPPORTED = 2,  /* valid but outside what the kernels cover */
+  MTS_ERR_LAUNCH = 3,       /* HIP runtime error at launch */
+  MTS_ERR_WORKSPACE = 4     /* workspace too small */
+} mts_status;
+
+typedef enum { MTS_F32 = 0, MTS_BF16 = 1 } mts_dtype;
+
+/* loss kinds: models/CRF.py:294-312 */
+typedef enum { MTS_LOSS_CE = 0, MTS_LOSS_BCE = 1, MTS_LOSS_FOCAL = 2 } mts_loss_kind;
+
+/* GEMM operand layouts.  C[M,N] = op(A) * op(B):
+ *   MTS_NT : A is [M,K] (K contiguous), B is [N,K] (K contiguous)   -- y = x W^T        (forward)
+ *   MTS_NN : A is [M,K] (K contiguous), B is [K,N] (N contiguous)   -- dx = dy W        (data grad)
+ *   MTS_TN : A is [K,M] (M contiguous), B is [K,N] (N contiguous)   -- dW = dy^T x      (weight grad)   */
+typedef enum { MTS_NT = 0, MTS_NN = 1, MTS_TN = 2 } mts_gemm_layout;
+
+/* epilogue flags for mts_gemm */
+#define MTS_EPI_BIAS      1u   /* += bias[n]  (fp32 [N])                                  */
+#define MTS_EPI_RESIDUAL  2u   /* += residual[m,n]  (act dtype, ld = ldr)                 */
+#define MTS_EPI_GELU      4u   /* C = gelu_erf(acc); pre-activation stored to `aux` if non-null */
+#define MTS_EPI_COLSCALE  8u   /* columns n < ncols_scaled are multiplied by colscale (q / sqrt(hd)) */
+#define MTS_EPI_ACCUM    16u   /* C += result (fp32 C only; used for split-K weight gradients) */
+
+const char* mts_last_error(void);
+/* version / build info: "mts-hip <n> gfx950" */
+const char* mts_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense projection GEMM (MFMA for bf16, exact-fp32 VALU kernel for parity mode).
+ * Replaces: nn.Linear inside HF Longformer (modeling_longformer.py:504-506, :1069, :1114, :1128),
+ * the LSTM input projection inside aten::lstm (models/NeuralArchitectures.py:113) and the tagger
+ * heads (models/CRF.py:299-310, :554-566); plus their autograd backward.
+ * a_dtype: dtype of A and B (and residual/aux); c_dtype: dtype of C (MTS_F32 or a_dtype).
+ * ------------------------------------------------------------------------------------------- */
+int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int M, int N, int K,
+             const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+             const float* bias, const void* residual, int ldr, void* aux, int ldaux,
+             unsigned epilogue, float colscale, int ncols_scaled);
+
+/* column sums of an [M,N] activation matrix into fp32 out[N] (bias gradients); deterministic two-stage
+ * reduction through `partial` (mts_colsum_workspace(N) bytes). */
+size_t mts_colsum_workspace(int N);
+int mts_colsum(void* stream, int dtype, int M, int N, const void* X, int ldx, float* out, int accumulate,
+               void* partial);
+
+/* fp32 -> act dtype copy (weights to bf16), n elements */
+int mts_cast(void* stream, int dst_dtype, const float* src, void* dst, size_t n);
+
+/* ---------------------------------------------------------------------------------------------
+ * LayerNorm family (biased variance, eps inside sqrt).
+ * Replaces: LongformerEmbeddings (modeling_longformer.py:402-426: x + pos_emb[2+i] + type_emb[0] -> LN),
+ * LongformerSelfOutput / LongformerOutput LayerNorm (:1068-1072, :1127-1131) and their backward.
+ * ------------------------------------------------------------------------------------------- */
+/* y[b,i,:] = LN(x[b,i,:] + pos[pos_offset+i,:] + type0[:]); x fp32 [B*L, D] (the batch as the collater made it);
+ * pre (act dtype, optional) receives the pre-LN sum for the backward; mean/rstd fp32 [B*L]. */
+int mts_embed_layernorm_fwd(void* stream, int dtype, int B, int L, int D, const float* x, const float* pos,
+                            int pos_offset, const float* type0, const float* gamma, const float* beta, float eps,
+                            void* y, void* pre, float* mean, float* rstd);
+/* If head_w != NULL the tagger head is fused in: scores[r,c] = y[r,:].head_w[c,:] + head_b[c] (fp32 [rows,n_out],
+ * n_out <= 4), computed on the stored (act dtype) y.  models/CRF.py:579 on top of modeling_longformer.py:1127-1131. */
+int mts_layernorm_fwd(void* stream, int dtype, int rows, int D, const void* x, const float* gamma,
+                      const float* beta, float eps, void* y, float* mean, float* rstd,
+                      const float* head_w, const float* head_b, int n_out, float* scores);
+/* dx = LN'(x) dy ; dgamma/dbeta (fp32 [D]) are OVERWRITTEN with the column reductions; dxsum (optional,
+ * fp32 [D]) receives colsum(dx) = the bias gradient of the linear layer that produced x.
+ * If head_w != NULL the incoming gradient is dy[r,:] (if non-null) + sum_c dlogit[r,c]*head_w[c,:]
+ * (the tagger head's data gradient fused in; n_out columns).
+ * partial: fp32 workspace of mts_layernorm_bwd_workspace(D) bytes. */
+size_t mts_layernorm_bwd_workspace(int D);
+int mts_layernorm_bwd(void* stream, int dtype, int rows, int D, const void* x, const void* dy,
+                      const float* dlogit, const float* head_w, int n_out,
+                      const float* gamma, const float* mean, const float* rstd,
+                      void* dx, float* dgamma, float* dbeta, float* dxsum, void* partial);
+/* gradient of the embedding sum: dpos[pos_offset+i,:] += sum_b dpre[b,i,:]; dtype0 += sum_{b,i} dpre
+ * (partial: 64*D floats of scratch) */
+int mts_embed_bwd(void* stream, int dtype, int B, int L, int D, const void* dpre, float* dpos, int pos_offset,
+                  float* dtype0, void* partial);
+
+/* dy *= gelu_erf'(u) in place (FFN backward; modeling_longformer.py:1113-1116); n elements, n % 4 == 0 */
+int mts_gelu_bwd(void* stream, int dtype, size_t n, const void* u, void* dy);
+
+/* ---------------------------------------------------------------------------------------------
+ * Restricted-window (band) self-attention.
+ * Replaces: LongformerSelfAttention.forward local path (modeling_longformer.py:482-640:
+ * _sliding_chunks_query_key_matmul :759-823, padding mask :524-536, softmax fp32 :574-576, masked
+ * query rows zeroed :579, _sliding_chunks_matmul_attn_probs_value :825-867) and, equivalently, the
+ * legacy per-position loop models/RestrictedTransformerLayer.py:509-636; plus the backward.
+ * qkv: [B*L, 3*D] act dtype, row = [q(D) | k(D) | v(D)], q already scaled; head h owns columns
+ * h*hd..(h+1)*hd of each third.  lengths: int32 [B] (NULL = all L).  ctx: [B*L, D].
+ * probs: fp32 [B*L, heads, slots] with slots = mts_band_slots(radius), saved for the backward.
+ * ------------------------------------------------------------------------------------------- */
+int mts_band_slots(int radius);
+int mts_band_attn_fwd(void* stream, int dtype, int B, int L, int D, int heads, int radius,
+                      const void* qkv, const int32_t* lengths, void* ctx, float* probs);
+/* dqkv [B*L, 3D] (dq already multiplied by q_scale so it is the gradient wrt the unscaled projection);
+ * dscores: fp32 scratch of the same size as probs. */
+int mts_band_attn_bwd(void* stream, int dtype, int B, int L, int D, int heads, int radius, float q_scale,
+                      const void* qkv, const int32_t* lengths, const float* probs, const void* dctx,
+                      void* dqkv, float* dscores);
+
+/* ---------------------------------------------------------------------------------------------
+ * Tagger head tail: loss + its gradient, and greedy decode.
+ * Replaces: the un-pad loop + BCE/Focal/CE of models/CRF.py:342-356 (=:447-461, :581-595),
+ * models/focal_loss.py:38-57, and decode models/CRF.py:362-369.
+ * scores: fp32 [B, L, n_out]; targets: fp32 [B, Lt] (pad -1 / 0 as the collater wrote them), Lt >= L;
+ * lengths int32 [B].  loss_out: fp32 [2] = {loss, number of rows averaged}.  dscores may be NULL.
+ * ------------------------------------------------------------------------------------------- */
+int mts_tagger_loss(void* stream, int loss_kind, int B, int L, int Lt, int n_out, const float* scores,
+                    const float* targets, const int32_t* lengths, float alpha, float gamma,
+                    float* loss_out, float* dscores);
+/* tags_out: uint8 [B, L]; positions >= length are 0.  prob > threshold, strict. */
+int mts_greedy_decode(void* stream, int B, int L, int n_out, const float* scores, const int32_t* lengths,
+                      float threshold, uint8_t* tags_out);
+/* scores[r, c] = x[r,:] . w[c,:] + b[c]  (x act dtype [rows, D]; w fp32 [n_out, D]); n_out in {1,2,4} */
+int mts_head_fwd(void* stream, int dtype, int rows, int D, int n_out, const void* x, int ldx, const float* w,
+                 const float* b, float* scores);
+/* dw[c,:] = sum_r dscores[r,c] x[r,:], db[c] = sum_r dscores[r,c] (OVERWRITE); workspace as layernorm_bwd */
+int mts_head_bwd_params(void* stream, int dtype, int rows, int D, int n_out, const void* x, int ldx,
+                        const float* dscores, float* dw, float* db, void* partial);
+/* dx[r,:] (+)= sum_c dscores[r,c] w[c,:] */
+int mts_head_bwd_data(void* stream, int dtype, int rows, int D, int n_out, const float* dscores, const float* w,
+                      void* dx, int lddx, int accumulate);
+
+/* ---------------------------------------------------------------------------------------------
+ * LSTM recurrence with packed-sequence semantics.
+ * Replaces: aten::lstm under pack_padded_sequence / pad_packed_sequence
+ * (models/NeuralArchitectures.py:98-115): gate order i,f,g,o, zero initial state, rows >= len are 0,
+ * the reverse direction starts at each document's own last sentence.
+ * xproj: [B*L, ndir*4H] act dtype = x W_ih^T + b_ih for both directions (direction d owns columns
+ *   d*4H..(d+1)*4H), produced by mts_gemm.  w_hh: fp32 [ndir, 4H, H]; b_hh: fp32 [ndir, 4H] (may be NULL),
+ *   added to the gate pre-activations in fp32 inside the recurrence.
+ * out: [B*L, ndir*H] act dtype.  gates (saved for backward): act dtype [B*L, ndir*4H] post-activation
+ *   i,f,g,o; cells: fp32 [B*L, ndir*H].
+ * ------------------------------------------------------------------------------------------- */
+/* workspace (both calls): mts_lstm_workspace(dtype, B, L, H, ndir) bytes */
+size_t mts_lstm_workspace(int dtype, int B, int L, int H, int ndir);
+int mts_lstm_fwd(void* stream, int dtype, int B, int L, int H, int ndir, const void* xproj, const float* w_hh,
+                 const float* b_hh, const int32_t* lengths, void* out, void* gates, float* cells, void* workspace);
+/* dxproj: [B*L, ndir*4H] act dtype (gradient wrt pre-activation gates); dw_hh fp32 [ndir,4H,H] OVERWRITTEN. */
+int mts_lstm_bwd(void* stream, int dtype, int B, int L, int H, int ndir, const float* w_hh, const int32_t* lengths,
+                 const void* out, const void* gates, const float* cells, const void* dout, void* dxproj,
+                 float* dw_hh, void* workspace);
+
+/* ---------------------------------------------------------------------------------------------
+ * CRF head.  Replaces models/CRF.py:98-240 (fc output = `feats` is produced by mts_gemm/mts_head_fwd).
+ * feats: fp32 [B, L, C]; C = num_tags + 2 (START = C-2, STOP = C-1); trans fp32 [C, C], T[i,j] = j -> i.
+ * ------------------------------------------------------------------------------------------- */
+/* loss_out[0] = mean_b(logZ_b - gold_b); dfeats [B,L,C] and dtrans [C,C] are OVERWRITTEN (may be NULL). */
+size_t mts_crf_workspace(int B, int L, int C);
+int mts_crf_nll(void* stream, int B, int L, int C, const float* feats, const float* tags, int Lt,
+                const int32_t* lengths, const float* trans, float* loss_out, float* dfeats, float* dtrans,
+                float* workspace /* mts_crf_workspace(B, L, C) bytes */);
+/* best_score fp32 [B]; paths int32 [B, L] (entries >= length undefined); bp_ws int32 [B, L, C] */
+int mts_crf_viterbi(void* stream, int B, int L, int C, const float* feats, const int32_t* lengths,
+                    const float* trans, float* best_score, int32_t* paths, int32_t* bp_ws);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimizer step over a flat fp32 parameter buffer.
+ * Replaces torch.optim.Adam(eps=1e-7) / SGD(momentum .9, wd 1e-4) of models/lightning_model.py:759-765.
+ * grad_scale multiplies the gradient first (1/world_size after an RCCL sum all-reduce).
+ * If bf16_copy != NULL the updated parameters are also written as bf16 (next step's GEMM weights).
+ * ------------------------------------------------------------------------------------------- */
+int mts_adam_step(void* stream, size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                  float lr, float beta1, float beta2, float eps, int step, float grad_scale, void* bf16_copy);
+int mts_sgd_step(void* stream, size_t n, float* param, const float* grad, float* momentum_buf, float lr,
+                 float momentum, float weight_decay, int first_step, float grad_scale, void* bf16_copy);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTS_H */

@@ -1,0 +1,108 @@
+"""ctypes binding of libmts_hip.so (the C ABI declared in include/mts.h).
+
+The product path has NO fallback: if the shared library is missing or fails to load, importing this
+module raises -- build it with ``python -m multimodaltopicsegmentation_amd.build`` (hipcc, gfx950).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmts_hip.so')
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f'{LIB_PATH} not found: the HIP kernel library has not been built. Run '
+        '`python -m multimodaltopicsegmentation_amd.build` (needs hipcc; cross-compiles for gfx950 without a GPU). '
+        'There is no CPU/PyTorch fallback for the tagger path.')
+
+lib = C.CDLL(LIB_PATH)
+
+F32, BF16 = 0, 1
+LOSS_CE, LOSS_BCE, LOSS_FOCAL = 0, 1, 2
+NT, NN, TN = 0, 1, 2
+EPI_BIAS, EPI_RESIDUAL, EPI_GELU, EPI_COLSCALE, EPI_ACCUM = 1, 2, 4, 8, 16
+
+_vp, _i, _f, _u, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint, C.c_size_t
+
+# name -> (restype, argtypes): must match include/mts.h exactly (tests/test_abi.py parses the header and checks)
+SIGNATURES = {
+    'mts_last_error': (C.c_char_p, []),
+    'mts_version': (C.c_char_p, []),
+    'mts_gemm': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _u, _f, _i]),
+    'mts_colsum_workspace': (_sz, [_i]),
+    'mts_colsum': (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
+    'mts_cast': (_i, [_vp, _i, _vp, _vp, _sz]),
+    'mts_embed_layernorm_fwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
+    'mts_layernorm_fwd': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    'mts_layernorm_bwd_workspace': (_sz, [_i]),
+    'mts_layernorm_bwd': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'mts_embed_bwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    'mts_gelu_bwd': (_i, [_vp, _i, _sz, _vp, _vp]),
+    'mts_band_slots': (_i, [_i]),
+    'mts_band_attn_fwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'mts_band_attn_bwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'mts_tagger_loss': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp]),
+    'mts_greedy_decode': (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp]),
+    'mts_head_fwd': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    'mts_head_bwd_params': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    'mts_head_bwd_data': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i]),
+    'mts_lstm_workspace': (_sz, [_i, _i, _i, _i, _i]),
+    'mts_lstm_fwd': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'mts_lstm_bwd': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'mts_crf_workspace': (_sz, [_i, _i, _i]),
+    'mts_crf_nll': (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'mts_crf_viterbi': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'mts_adam_step': (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i, _f, _vp]),
+    'mts_sgd_step': (_i, [_vp, _sz, _vp, _vp, _vp, _f, _f, _f, _i, _f, _vp]),
+}
+
+_missing = []
+for _name, (_res, _args) in SIGNATURES.items():
+    try:
+        _fn = getattr(lib, _name)
+    except AttributeError:
+        _missing.append(_name)
+        continue
+    _fn.restype = _res
+    _fn.argtypes = _args
+if _missing:
+    raise ImportError(f'{LIB_PATH} does not export {_missing}: stale build? re-run python -m multimodaltopicsegmentation_amd.build --force')
+
+
+class MtsError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib.mts_last_error().decode('utf-8', 'replace')
+        if rc == 1:
+            raise ValueError(msg)                       # MTS_ERR_INVALID  <-> the reference's ValueError / asserts
+        if rc == 2:
+            raise NotImplementedError(msg)              # MTS_ERR_UNSUPPORTED
+        raise MtsError(f'mts error {rc}: {msg}')
+
+
+def stream_ptr():
+    """Raw hipStream_t of torch's current stream (kernels are enqueued on it, so torch ordering rules apply)."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise ValueError(f'unsupported activation dtype {dt}')
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError('multimodaltopicsegmentation_amd: no GPU visible. The tagger path runs only on its HIP kernels '
+                           '(MI355X / gfx950); there is no CPU fallback.')

@@ -1,0 +1,477 @@
+// Dense projection GEMMs for gfx950.
+//
+//   gemm_bf16_kernel : bf16 operands, fp32 accumulate on the matrix cores (v_mfma_f32_16x16x32_bf16),
+//                      128x128x64 block tile, 4 waves (2x2) of 64x64, register-staged global->LDS with
+//                      the next tile's loads in flight behind the current tile's MFMAs, double-buffered
+//                      LDS (one barrier per K-step), XOR-swizzled LDS images so that both the row-wise
+//                      ds_read_b128 fragment reads and the transposed ds_read_b64_tr_b16 reads are
+//                      bank-conflict free.  All three layouts of mts.h (NT/NN/TN) share the kernel:
+//                      a K-contiguous operand is read row-wise, an M-/N-contiguous operand through the
+//                      hardware transpose read, so neither activations nor weights are ever transposed
+//                      in HBM.
+//   gemm_f32_kernel  : exact-fp32 VALU kernel with arbitrary strides (parity mode; deterministic).
+//
+// The accumulator tile is computed TRANSPOSED (the W fragment is the MFMA A operand) so that each lane
+// ends up with 4 consecutive output columns of one row: bias/residual/aux/C are accessed as 8/16-byte
+// vectors in the epilogue.
+#include <algorithm>
+#include <math.h>
+#include "common.h"
+
+struct GemmArgs {
+  const void* A; const void* B; void* C;
+  const float* bias; const void* residual; void* aux;
+  int M, N, K;
+  int lda, ldb, ldc, ldr, ldaux;
+  unsigned epi;
+  float colscale; int ncols_scaled;
+  int ksplit;      // K elements per blockIdx.z slice (multiple of 64)
+  int atomic_out;  // 1: fp32 atomicAdd into C (split-K)
+};
+
+// ------------------------------------------------------------------------------------------------
+// shared epilogue: lane owns C[m][n..n+3]
+// ------------------------------------------------------------------------------------------------
+template <typename TA, typename TC>
+__device__ __forceinline__ void epilogue4(const GemmArgs& a, int m, int n, float (&v)[4], bool first_slice) {
+  if (m >= a.M || n >= a.N) return;
+  const unsigned epi = a.epi;
+  const bool full = (n + 3 < a.N);
+  if (full) {
+    if ((epi & MTS_EPI_BIAS) && first_slice) {
+      const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+      v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if (epi & MTS_EPI_COLSCALE) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) if (n + i < a.ncols_scaled) v[i] *= a.colscale;
+    }
+    if ((epi & MTS_EPI_RESIDUAL) && first_slice) {
+      float r[4];
+      load4<TA>(reinterpret_cast<const TA*>(a.residual) + (size_t)m * a.ldr + n, r);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += r[i];
+    }
+    if (epi & MTS_EPI_GELU) {
+      if (a.aux) store4<TA>(reinterpret_cast<TA*>(a.aux) + (size_t)m * a.ldaux + n, v);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = gelu_erf_f(v[i]);
+    }
+    TC* c = reinterpret_cast<TC*>(a.C) + (size_t)m * a.ldc + n;
+    if constexpr (sizeof(TC) == 4) {
+      float* cf = reinterpret_cast<float*>(c);
+      if (a.atomic_out) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(cf + i, v[i]);
+      } else if (epi & MTS_EPI_ACCUM) {
+        float o[4];
+        load4<float>(cf, o);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] += v[i];
+        store4<float>(cf, o);
+      } else {
+        store4<float>(cf, v);
+      }
+    } else {
+      store4<TC>(c, v);
+    }
+  } else {
+    for (int i = 0; i < 4 && n + i < a.N; ++i) {
+      float x = v[i];
+      if ((epi & MTS_EPI_BIAS) && first_slice) x += a.bias[n + i];
+      if ((epi & MTS_EPI_COLSCALE) && n + i < a.ncols_scaled) x *= a.colscale;
+      if ((epi & MTS_EPI_RESIDUAL) && first_slice) x += to_f32(reinterpret_cast<const TA*>(a.residual)[(size_t)m * a.ldr + n + i]);
+      if (epi & MTS_EPI_GELU) {
+        if (a.aux) reinterpret_cast<TA*>(a.aux)[(size_t)m * a.ldaux + n + i] = from_f32<TA>(x);
+        x = gelu_erf_f(x);
+      }
+      TC* c = reinterpret_cast<TC*>(a.C) + (size_t)m * a.ldc + n + i;
+      if constexpr (sizeof(TC) == 4) {
+        float* cf = reinterpret_cast<float*>(c);
+        if (a.atomic_out) atomicAdd(cf, x);
+        else if (epi & MTS_EPI_ACCUM) *cf += x;
+        else *cf = x;
+      } else {
+        *c = from_f32<TC>(x);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 MFMA kernel
+// ------------------------------------------------------------------------------------------------
+#define BM 128
+#define BN 128
+#define BK 64
+#define TILE_BYTES (128 * 64 * 2)  // one operand stage = 16 KiB in either image
+
+// K-major image: [128 rows][64 k] bf16, 128-B rows, 16-B chunk index XORed with (row>>1)&7.
+__device__ __forceinline__ int kmajor_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// strided image: [64 k-rows][128 cols] bf16, 256-B rows, 32-B chunk index XORed with key(krow).
+__device__ __forceinline__ int strided_key(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
+__device__ __forceinline__ int strided_off(int krow, int col) {
+  return krow * 256 + ((((col >> 4) ^ strided_key(krow))) << 5) + ((col & 15) << 1);
+}
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ bf16x8 frag_kmajor(const char* tile, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8*>(tile + kmajor_off(row, chunk));
+}
+// fragment X[k = kbase + 0..7][c = c0 + (lane&15)] of a strided image through two transposed reads
+__device__ __forceinline__ bf16x8 frag_strided(const char* tile, int kbase, int c0, int lane) {
+  const int r = lane & 15;
+  const int q = r >> 2, p = r & 3;
+  const int col = c0 + 4 * p;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + strided_off(kbase + q, col)));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + strided_off(kbase + 4 + q, col)));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int LAYOUT, typename TC>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
+  constexpr bool A_KMAJOR = (LAYOUT != MTS_TN);
+  constexpr bool B_KMAJOR = (LAYOUT == MTS_NT);
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A stage | B stage]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r16 = lane & 15, g = lane >> 4;
+
+  // XCD-aware tile order: blocks b, b+8, b+16.. share an XCD (round-robin dispatch), so give each XCD a
+  // contiguous run of tiles; consecutive tiles walk N first, sharing the same A panel in that XCD's L2.
+  const int ntn = (a.N + BN - 1) / BN;
+  const int ntm = (a.M + BM - 1) / BM;
+  const int nt = ntn * ntm;
+  int bid = blockIdx.x;
+  {
+    const int q = nt >> 3, rr = nt & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+  }
+  const int bm0 = (bid / ntn) * BM;
+  const int bn0 = (bid % ntn) * BN;
+  const int kbeg = blockIdx.z * a.ksplit;
+  const int kend = min(a.K, kbeg + a.ksplit);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(a.A);
+  const bf16_t* __restrict__ B = reinterpret_cast<const bf16_t*>(a.B);
+
+  uint4 ra[4], rb[4];
+  auto load_tile = [&](int kt) {
+    const int k0 = kbeg + kt * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i;
+      if constexpr (A_KMAJOR) {
+        const int row = c >> 3, ch = c & 7;
+        const int gm = bm0 + row, gk = k0 + ch * 8;
+        ra[i] = (gm < a.M && gk < kend) ? *reinterpret_cast<const uint4*>(A + (size_t)gm * a.lda + gk) : make_uint4(0, 0, 0, 0);
+      } else {
+        const int kr = c >> 4, ch = c & 15;
+        const int gk = k0 + kr, gm = bm0 + ch * 8;
+        ra[i] = (gk < kend && gm < a.M) ? *reinterpret_cast<const uint4*>(A + (size_t)gk * a.lda + gm) : make_uint4(0, 0, 0, 0);
+      }
+      if constexpr (B_KMAJOR) {
+        const int row = c >> 3, ch = c & 7;
+        const int gn = bn0 + row, gk = k0 + ch * 8;
+        rb[i] = (gn < a.N && gk < kend) ? *reinterpret_cast<const uint4*>(B + (size_t)gn * a.ldb + gk) : make_uint4(0, 0, 0, 0);
+      } else {
+        const int kr = c >> 4, ch = c & 15;
+        const int gk = k0 + kr, gn = bn0 + ch * 8;
+        rb[i] = (gk < kend && gn < a.N) ? *reinterpret_cast<const uint4*>(B + (size_t)gk * a.ldb + gn) : make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* sa = smem + buf * (2 * TILE_BYTES);
+    char* sb = sa + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i;
+      if constexpr (A_KMAJOR) {
+        *reinterpret_cast<uint4*>(sa + kmajor_off(c >> 3, c & 7)) = ra[i];
+      } else {
+        const int kr = c >> 4, ch = c & 15;
+        *reinterpret_cast<uint4*>(sa + kr * 256 + ((((ch >> 1) ^ strided_key(kr))) << 5) + ((ch & 1) << 4)) = ra[i];
+      }
+      if constexpr (B_KMAJOR) {
+        *reinterpret_cast<uint4*>(sb + kmajor_off(c >> 3, c & 7)) = rb[i];
+      } else {
+        const int kr = c >> 4, ch = c & 15;
+        *reinterpret_cast<uint4*>(sb + kr * 256 + ((((ch >> 1) ^ strided_key(kr))) << 5) + ((ch & 1) << 4)) = rb[i];
+      }
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);  // global loads stay in flight behind the MFMAs below
+    const char* sa = smem + buf * (2 * TILE_BYTES);
+    const char* sb = sa + TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (A_KMAJOR) af[i] = frag_kmajor(sa, wm * 64 + i * 16 + r16, ks * 4 + g);
+        else af[i] = frag_strided(sa, ks * 32 + 8 * g, wm * 64 + i * 16, lane);
+        if constexpr (B_KMAJOR) bfr[i] = frag_kmajor(sb, wn * 64 + i * 16 + r16, ks * 4 + g);
+        else bfr[i] = frag_strided(sb, ks * 32 + 8 * g, wn * 64 + i * 16, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // C^T tile
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  const bool first_slice = (blockIdx.z == 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = bm0 + wm * 64 + i * 16 + r16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = bn0 + wn * 64 + j * 16 + 4 * g;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      epilogue4<bf16_t, TC>(a, m, n, v, first_slice);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 VALU kernel, arbitrary strides: C[m,n] = sum_k A[m*sam + k*sak] * B[n*sbn + k*sbk]
+// 64x64 tile, BK = 16, 256 threads, 4x4 outputs per thread (columns n0 + tx*4 .. +3, rows m0 + ty + 16*i)
+// ------------------------------------------------------------------------------------------------
+struct StrideArgs { long sam, sak, sbn, sbk; };
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs a, const StrideArgs s) {
+  __shared__ float As[16][64 + 4];
+  __shared__ float Bs[16][64 + 4];
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int ntn = (a.N + 63) / 64;
+  const int bm0 = (blockIdx.x / ntn) * 64, bn0 = (blockIdx.x % ntn) * 64;
+  const float* __restrict__ A = reinterpret_cast<const float*>(a.A);
+  const float* __restrict__ B = reinterpret_cast<const float*>(a.B);
+  float acc[4][4] = {};
+  for (int k0 = 0; k0 < a.K; k0 += 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i;
+      int m, k;
+      if (s.sak == 1) { m = e >> 4; k = e & 15; } else { m = e & 63; k = e >> 6; }
+      As[k][m] = (bm0 + m < a.M && k0 + k < a.K) ? A[(long)(bm0 + m) * s.sam + (long)(k0 + k) * s.sak] : 0.f;
+      int n, kb;
+      if (s.sbk == 1) { n = e >> 4; kb = e & 15; } else { n = e & 63; kb = e >> 6; }
+      Bs[kb][n] = (bn0 + n < a.N && k0 + kb < a.K) ? B[(long)(bn0 + n) * s.sbn + (long)(k0 + kb) * s.sbk] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) av[i] = As[k][ty + 16 * i];
+      const float4 b4 = *reinterpret_cast<const float4*>(&Bs[k][tx * 4]);
+      bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float v[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+    epilogue4<float, float>(a, bm0 + ty + 16 * i, bn0 + tx * 4, v, true);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums (bias gradients): two deterministic stages
+// ------------------------------------------------------------------------------------------------
+#define COLSUM_RS 128
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ X, int M, int N, int ldx,
+                                                             float* __restrict__ partial) {
+  const int n = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (n >= N) return;
+  const int rs = blockIdx.y;
+  const int rows_per = (M + COLSUM_RS - 1) / COLSUM_RS;
+  const int m0 = rs * rows_per, m1 = min(M, m0 + rows_per);
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (n + 3 < N) {
+    for (int m = m0; m < m1; ++m) {
+      float v[4];
+      load4<T>(X + (size_t)m * ldx + n, v);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s[i] += v[i];
+    }
+  } else {
+    for (int m = m0; m < m1; ++m)
+      for (int i = 0; i < 4 && n + i < N; ++i) s[i] += to_f32(X[(size_t)m * ldx + n + i]);
+  }
+  for (int i = 0; i < 4 && n + i < N; ++i) partial[(size_t)rs * N + n + i] = s[i];
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int N, int nparts,
+                                                           float* __restrict__ out, int accumulate) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int r = 0; r < nparts; ++r) s += partial[(size_t)r * N + n];
+  out[n] = accumulate ? out[n] + s : s;
+}
+
+template <typename T> __global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, size_t n) {
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+  for (; i + 3 < n; i += stride) {
+    float v[4];
+    load4<float>(src + i, v);
+    store4<T>(dst + i, v);
+  }
+  // tail (n % 4 elements) handled by the thread that lands on it
+  if (i < n && i + 3 >= n)
+    for (size_t j = i; j < n; ++j) dst[j] = from_f32<T>(src[j]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+extern "C" size_t mts_colsum_workspace(int N) { return (size_t)COLSUM_RS * (size_t)N * sizeof(float); }
+
+extern "C" int mts_colsum(void* stream, int dtype, int M, int N, const void* X, int ldx, float* out, int accumulate,
+                          void* partial) {
+  MTS_CHECK_ARG(M > 0 && N > 0 && X && out && partial, "mts_colsum: bad arguments");
+  MTS_CHECK_ARG(dtype == MTS_F32 || dtype == MTS_BF16, "mts_colsum: bad dtype %d", dtype);
+  MTS_CHECK_ARG(ldx % 4 == 0, "mts_colsum: ldx must be a multiple of 4");
+  hipStream_t st = (hipStream_t)stream;
+  const int nparts = min(COLSUM_RS, M);
+  dim3 grid(ceil_div(ceil_div(N, 4), 256), COLSUM_RS);
+  // rows_per = ceil(M / RS): slices past M write zeros (m0 >= m1), so all RS partials are defined
+  (void)nparts;
+  if (dtype == MTS_F32)
+    hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, st, (const float*)X, M, N, ldx, (float*)partial);
+  else
+    hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)X, M, N, ldx, (float*)partial);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, (const float*)partial, N, COLSUM_RS, out,
+                     accumulate);
+  MTS_LAUNCH_CHECK("mts_colsum");
+  return MTS_OK;
+}
+
+extern "C" int mts_cast(void* stream, int dst_dtype, const float* src, void* dst, size_t n) {
+  MTS_CHECK_ARG(src && dst, "mts_cast: null pointer");
+  if (n == 0) return MTS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = (int)std::min<size_t>(2048, (n / 4 + 255) / 256 + 1);
+  if (dst_dtype == MTS_BF16)
+    hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, src, (bf16_t*)dst, n);
+  else if (dst_dtype == MTS_F32)
+    hipLaunchKernelGGL(cast_kernel<float>, dim3(blocks), dim3(256), 0, st, src, (float*)dst, n);
+  else {
+    mts_set_error("mts_cast: bad dtype %d", dst_dtype);
+    return MTS_ERR_INVALID;
+  }
+  MTS_LAUNCH_CHECK("mts_cast");
+  return MTS_OK;
+}
+
+template <int LAYOUT, typename TC>
+static void launch_bf16(const GemmArgs& a, int splits, hipStream_t st) {
+  const int nt = ceil_div(a.M, BM) * ceil_div(a.N, BN);
+  hipLaunchKernelGGL((gemm_bf16_kernel<LAYOUT, TC>), dim3(nt, 1, splits), dim3(256), 4 * TILE_BYTES, st, a);
+}
+
+extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int M, int N, int K, const void* A, int lda,
+                        const void* B, int ldb, void* C, int ldc, const float* bias, const void* residual, int ldr,
+                        void* aux, int ldaux, unsigned epilogue, float colscale, int ncols_scaled) {
+  MTS_CHECK_ARG(M > 0 && N > 0 && K > 0, "mts_gemm: bad shape M=%d N=%d K=%d", M, N, K);
+  MTS_CHECK_ARG(A && B && C, "mts_gemm: null operand");
+  MTS_CHECK_ARG(layout == MTS_NT || layout == MTS_NN || layout == MTS_TN, "mts_gemm: bad layout %d", layout);
+  MTS_CHECK_ARG(a_dtype == MTS_F32 || a_dtype == MTS_BF16, "mts_gemm: bad a_dtype %d", a_dtype);
+  MTS_CHECK_ARG(c_dtype == MTS_F32 || c_dtype == a_dtype, "mts_gemm: c_dtype must be f32 or a_dtype");
+  MTS_CHECK_ARG(!(epilogue & MTS_EPI_BIAS) || bias, "mts_gemm: MTS_EPI_BIAS without bias");
+  MTS_CHECK_ARG(!(epilogue & MTS_EPI_RESIDUAL) || residual, "mts_gemm: MTS_EPI_RESIDUAL without residual");
+  MTS_CHECK_ARG(!(epilogue & MTS_EPI_ACCUM) || c_dtype == MTS_F32, "mts_gemm: MTS_EPI_ACCUM needs fp32 C");
+  hipStream_t st = (hipStream_t)stream;
+  GemmArgs a;
+  a.A = A; a.B = B; a.C = C; a.bias = bias; a.residual = residual; a.aux = aux;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.ldaux = ldaux;
+  a.epi = epilogue; a.colscale = colscale; a.ncols_scaled = ncols_scaled;
+  a.ksplit = K; a.atomic_out = 0;
+
+  if (a_dtype == MTS_F32) {
+    StrideArgs s;
+    if (layout == MTS_NT) { s.sam = lda; s.sak = 1; s.sbn = ldb; s.sbk = 1; }
+    else if (layout == MTS_NN) { s.sam = lda; s.sak = 1; s.sbn = 1; s.sbk = ldb; }
+    else { s.sam = 1; s.sak = lda; s.sbn = 1; s.sbk = ldb; }
+    MTS_CHECK_ARG(ldc % 4 == 0 && ((uintptr_t)C % 16) == 0, "mts_gemm(f32): C must be 16-byte aligned with ldc %% 4 == 0");
+    MTS_CHECK_ARG(!(epilogue & MTS_EPI_RESIDUAL) || (ldr % 4 == 0), "mts_gemm(f32): ldr %% 4");
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3(ceil_div(M, 64) * ceil_div(N, 64)), dim3(256), 0, st, a, s);
+    MTS_LAUNCH_CHECK("mts_gemm(f32)");
+    return MTS_OK;
+  }
+
+  // bf16 MFMA path: 16-byte vector accesses along the contiguous dimension of every operand
+  MTS_UNSUPPORTED(lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0,
+                  "mts_gemm(bf16): A/B must be 16-byte aligned with ld %% 8 == 0 (lda=%d ldb=%d)", lda, ldb);
+  if (layout == MTS_NT) MTS_UNSUPPORTED(K % 8 == 0, "mts_gemm(bf16,NT): K %% 8 != 0 (K=%d)", K);
+  if (layout == MTS_NN) MTS_UNSUPPORTED(K % 8 == 0 && N % 8 == 0, "mts_gemm(bf16,NN): K,N %% 8 (K=%d N=%d)", K, N);
+  if (layout == MTS_TN) MTS_UNSUPPORTED(M % 8 == 0 && N % 8 == 0, "mts_gemm(bf16,TN): M,N %% 8 (M=%d N=%d)", M, N);
+  MTS_UNSUPPORTED(ldc % 4 == 0 && ((uintptr_t)C % (c_dtype == MTS_F32 ? 16 : 8)) == 0, "mts_gemm(bf16): C alignment/ldc");
+  MTS_UNSUPPORTED(!(epilogue & MTS_EPI_RESIDUAL) || (ldr % 4 == 0 && ((uintptr_t)residual % 8) == 0), "mts_gemm(bf16): residual alignment");
+  MTS_UNSUPPORTED(!aux || (ldaux % 4 == 0 && ((uintptr_t)aux % 8) == 0), "mts_gemm(bf16): aux alignment");
+
+  int splits = 1;
+  if (c_dtype == MTS_F32 && !(epilogue & MTS_EPI_GELU)) {
+    // weight-gradient shapes: few output tiles, very long K -> split K over blockIdx.z (fp32 atomics)
+    const int nt = ceil_div(M, BM) * ceil_div(N, BN);
+    const int want = ceil_div(2048, nt);
+    const int maxs = K / 1024;
+    splits = want < 1 ? 1 : want;
+    if (splits > maxs) splits = maxs;
+    if (splits < 1) splits = 1;
+  }
+  if (splits > 1) {
+    a.ksplit = ceil_div(ceil_div(K, splits), BK) * BK;
+    splits = ceil_div(K, a.ksplit);
+    a.atomic_out = 1;
+    if (!(epilogue & MTS_EPI_ACCUM)) {
+      hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, st);
+      if (e != hipSuccess) { mts_set_error("mts_gemm: memset failed: %s", hipGetErrorString(e)); return MTS_ERR_LAUNCH; }
+    }
+  }
+  if (c_dtype == MTS_F32) {
+    if (layout == MTS_NT) launch_bf16<MTS_NT, float>(a, splits, st);
+    else if (layout == MTS_NN) launch_bf16<MTS_NN, float>(a, splits, st);
+    else launch_bf16<MTS_TN, float>(a, splits, st);
+  } else {
+    if (layout == MTS_NT) launch_bf16<MTS_NT, bf16_t>(a, splits, st);
+    else if (layout == MTS_NN) launch_bf16<MTS_NN, bf16_t>(a, splits, st);
+    else launch_bf16<MTS_TN, bf16_t>(a, splits, st);
+  }
+  MTS_LAUNCH_CHECK("mts_gemm(bf16)");
+  return MTS_OK;
+}

@@ -1,0 +1,617 @@
+// Row-wise HBM-bound kernels: embedding-sum + LayerNorm, LayerNorm fwd/bwd, tagger head fwd/bwd.
+//
+// Mapping: one 64-lane wave per row, the row lives in registers as NV vectors of 4 elements per lane
+// (lane l owns elements 4*(l + 64*v) .. +3, v < NV), so every global access is a coalesced 8/16-byte
+// vector and each row is read exactly once; statistics are fp32 wave reductions (DPP/shuffle), never LDS.
+// Column reductions (dgamma, dbeta, bias gradients, head weight gradient) are accumulated in registers
+// over the rows a wave visits, combined per workgroup through LDS and finished by a second tiny kernel
+// over the per-workgroup slabs -> bitwise reproducible (no float atomics).
+#include <algorithm>
+#include <type_traits>
+#include "common.h"
+
+#define ROW_WAVES 4            // waves (= rows in flight) per workgroup
+#define BWD_MAX_BLOCKS 512
+
+template <typename T, int NV> struct RowRegs {
+  float v[NV][4];
+  __device__ __forceinline__ void load(const T* row, int D, int lane) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = 4 * (lane + 64 * i);
+      if (e < D) load4<T>(row + e, v[i]);
+      else { v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f; }
+    }
+  }
+  __device__ __forceinline__ void store(T* row, int D, int lane) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = 4 * (lane + 64 * i);
+      if (e < D) store4<T>(row + e, v[i]);
+    }
+  }
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
+  }
+};
+
+template <int NV> __device__ __forceinline__ void row_stats(const float (&x)[NV][4], int D, int lane, float& mean, float& rstd, float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]);
+  mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (4 * (lane + 64 * i) < D) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float d = x[i][j] - mean; q += d * d; }
+    }
+  }
+  rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NV, bool EMBED>
+__global__ __launch_bounds__(64 * ROW_WAVES) void ln_fwd_kernel(
+    const void* __restrict__ xin, const float* __restrict__ pos, int pos_offset, int L, const float* __restrict__ type0,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int rows, int D,
+    T* __restrict__ y, T* __restrict__ pre, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+    const float* __restrict__ head_w, const float* __restrict__ head_b, int n_out, float* __restrict__ scores) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * ROW_WAVES + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float x[NV][4];
+  if constexpr (EMBED) {
+    const float* xr = reinterpret_cast<const float*>(xin) + (size_t)row * D;
+    const float* pr = pos + (size_t)(pos_offset + row % L) * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = 4 * (lane + 64 * i);
+      if (e < D) {
+        float a[4], b[4], c[4];
+        load4<float>(xr + e, a); load4<float>(pr + e, b); load4<float>(type0 + e, c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[i][j] = (a[j] + b[j]) + c[j];   // same association as HF:421
+        if constexpr (sizeof(T) == 2) {
+          // the backward re-reads `pre` in storage precision: normalise exactly what was stored
+#pragma unroll
+          for (int j = 0; j < 4; ++j) x[i][j] = to_f32(from_f32<T>(x[i][j]));
+        }
+      } else { x[i][0] = x[i][1] = x[i][2] = x[i][3] = 0.f; }
+    }
+    if (pre) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) { const int e = 4 * (lane + 64 * i); if (e < D) store4<T>(pre + (size_t)row * D + e, x[i]); }
+    }
+  } else {
+    const T* xr = reinterpret_cast<const T*>(xin) + (size_t)row * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = 4 * (lane + 64 * i);
+      if (e < D) load4<T>(xr + e, x[i]);
+      else { x[i][0] = x[i][1] = x[i][2] = x[i][3] = 0.f; }
+    }
+  }
+  float mean, rstd;
+  row_stats<NV>(x, D, lane, mean, rstd, eps);
+  float hs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int e = 4 * (lane + 64 * i);
+    if (e < D) {
+      float g[4], b[4], o[4];
+      load4<float>(gamma + e, g); load4<float>(beta + e, b);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (x[i][j] - mean) * rstd * g[j] + b[j];
+      store4<T>(y + (size_t)row * D + e, o);
+      if (head_w) {  // fused tagger head on the value that was stored (storage precision)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (c < n_out) {
+            float w[4];
+            load4<float>(head_w + (size_t)c * D + e, w);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hs[c] += to_f32(from_f32<T>(o[j])) * w[j];
+          }
+        }
+      }
+    }
+  }
+  if (lane == 0 && mean_out) { mean_out[row] = mean; rstd_out[row] = rstd; }
+  if (head_w) {
+    for (int c = 0; c < n_out; ++c) {
+      const float s = wave_sum(hs[c]);
+      if (lane == 0) scores[(size_t)row * n_out + c] = s + head_b[c];
+    }
+  }
+}
+
+// scores = x w^T + b for small n_out (1, 2 or 4): one wave per row
+template <typename T>
+__global__ __launch_bounds__(64 * ROW_WAVES) void head_fwd_kernel(const T* __restrict__ x, int ldx, int rows, int D, int n_out,
+                                                                const float* __restrict__ w, const float* __restrict__ b,
+                                                                float* __restrict__ scores) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * ROW_WAVES + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float hs[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int e = 4 * lane; e < D; e += 256) {
+    float xv[4];
+    load4<T>(x + (size_t)row * ldx + e, xv);
+    for (int c = 0; c < n_out; ++c) {
+      float wv[4];
+      load4<float>(w + (size_t)c * D + e, wv);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) hs[c] += xv[j] * wv[j];
+    }
+  }
+  for (int c = 0; c < n_out; ++c) {
+    const float s = wave_sum(hs[c]);
+    if (lane == 0) scores[(size_t)row * n_out + c] = s + b[c];
+  }
+}
+
+// dx[r,:] (+)= sum_c ds[r,c] w[c,:]
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_data_kernel(const float* __restrict__ ds, const float* __restrict__ w, int rows, int D,
+                                                            int n_out, T* __restrict__ dx, int lddx, int accumulate) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int per_row = D / 4;
+  const size_t total = (size_t)rows * per_row;
+  if (idx >= total) return;
+  const int row = (int)(idx / per_row);
+  const int e = 4 * (int)(idx % per_row);
+  float o[4] = {0.f, 0.f, 0.f, 0.f};
+  if (accumulate) load4<T>(dx + (size_t)row * lddx + e, o);
+  for (int c = 0; c < n_out; ++c) {
+    const float s = ds[(size_t)row * n_out + c];
+    float wv[4];
+    load4<float>(w + (size_t)c * D + e, wv);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] += s * wv[j];
+  }
+  store4<T>(dx + (size_t)row * lddx + e, o);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: per-row dx + register-accumulated column reductions
+//   slab layout (fp32): partial[block][slot][D], slots: 0 dgamma, 1 dbeta, 2 colsum(dx)
+//   MODE 0: LayerNorm backward.  MODE 1: head parameter gradient (slots 0..n_out-1 = dw rows; db via slot 4.. see below)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NV>
+__global__ __launch_bounds__(64 * ROW_WAVES) void ln_bwd_kernel(
+    const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ dlogit, const float* __restrict__ head_w, int n_out,
+    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd, int rows, int D,
+    T* __restrict__ dx, float* __restrict__ partial) {
+  __shared__ float red[ROW_WAVES][3][64 * 4];   // one vector slot at a time is combined through LDS
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  float g_[NV][4];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int e = 4 * (lane + 64 * i);
+    if (e < D) load4<float>(gamma + e, g_[i]);
+    else { g_[i][0] = g_[i][1] = g_[i][2] = g_[i][3] = 0.f; }
+  }
+  float dg[NV][4], db[NV][4], dxs[NV][4];
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dg[i][j] = db[i][j] = dxs[i][j] = 0.f;
+
+  const float invD = 1.0f / (float)D;
+  for (int row = blockIdx.x * ROW_WAVES + wave; row < rows; row += gridDim.x * ROW_WAVES) {
+    const float mu = mean[row], rs = rstd[row];
+    float xh[NV][4], gy[NV][4];
+    float s1 = 0.f, s2 = 0.f;
+    float dl[4] = {0.f, 0.f, 0.f, 0.f};
+    if (head_w) for (int c = 0; c < n_out; ++c) dl[c] = dlogit[(size_t)row * n_out + c];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = 4 * (lane + 64 * i);
+      if (e < D) {
+        float xv[4], dv[4] = {0.f, 0.f, 0.f, 0.f};
+        load4<T>(x + (size_t)row * D + e, xv);
+        if (dy) load4<T>(dy + (size_t)row * D + e, dv);
+        if (head_w) {
+          for (int c = 0; c < n_out; ++c) {
+            float wv[4];
+            load4<float>(head_w + (size_t)c * D + e, wv);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dv[j] += dl[c] * wv[j];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xh[i][j] = (xv[j] - mu) * rs;
+          gy[i][j] = dv[j] * g_[i][j];
+          s1 += gy[i][j];
+          s2 += gy[i][j] * xh[i][j];
+          dg[i][j] += dv[j] * xh[i][j];
+          db[i][j] += dv[j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { xh[i][j] = 0.f; gy[i][j] = 0.f; }
+      }
+    }
+    s1 = wave_sum(s1) * invD;
+    s2 = wave_sum(s2) * invD;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = 4 * (lane + 64 * i);
+      if (e < D) {
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o[j] = rs * (gy[i][j] - s1 - xh[i][j] * s2);
+          if constexpr (sizeof(T) == 2) o[j] = to_f32(from_f32<T>(o[j]));   // sum what is stored
+          dxs[i][j] += o[j];
+        }
+        store4<T>(dx + (size_t)row * D + e, o);
+      }
+    }
+  }
+  // combine the ROW_WAVES waves of this workgroup, one vector slot (256 columns) at a time
+  float* slab = partial + (size_t)blockIdx.x * 3 * D;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      red[wave][0][lane * 4 + j] = dg[i][j];
+      red[wave][1][lane * 4 + j] = db[i][j];
+      red[wave][2][lane * 4 + j] = dxs[i][j];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 3 * 256; t += 64 * ROW_WAVES) {
+      const int slot = t / 256, col = t % 256;
+      const int e = 256 * i + col;
+      if (e < D) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < ROW_WAVES; ++w) s += red[w][slot][col];
+        slab[(size_t)slot * D + e] = s;
+      }
+    }
+  }
+}
+
+// head parameter gradient: dw[c,:] = sum_r ds[r,c] x[r,:]   (slab slots 0..3 = c); db handled by the final kernel
+template <typename T, int NV>
+__global__ __launch_bounds__(64 * ROW_WAVES) void head_bwd_params_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ ds,
+                                                                       int n_out, int rows, int D, float* __restrict__ partial) {
+  __shared__ float red[ROW_WAVES][4][64 * 4];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  float dw[4][NV][4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dw[c][i][j] = 0.f;
+  float dbs[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int row = blockIdx.x * ROW_WAVES + wave; row < rows; row += gridDim.x * ROW_WAVES) {
+    float dl[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < n_out; ++c) dl[c] = ds[(size_t)row * n_out + c];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dbs[c] += dl[c];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = 4 * (lane + 64 * i);
+      if (e < D) {
+        float xv[4];
+        load4<T>(x + (size_t)row * ldx + e, xv);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dw[c][i][j] += dl[c] * xv[j];
+      }
+    }
+  }
+  // slab: [block][5][D] -> slots 0..3 dw rows, slot 4: first 4 entries = db partial of this workgroup
+  float* slab = partial + (size_t)blockIdx.x * 5 * D;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[wave][c][lane * 4 + j] = dw[c][i][j];
+    __syncthreads();
+    for (int t = threadIdx.x; t < 4 * 256; t += 64 * ROW_WAVES) {
+      const int slot = t / 256, col = t % 256;
+      const int e = 256 * i + col;
+      if (e < D) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < ROW_WAVES; ++w) s += red[w][slot][col];
+        slab[(size_t)slot * D + e] = s;
+      }
+    }
+  }
+  __syncthreads();
+  if (lane == 0)
+    for (int c = 0; c < 4; ++c) red[wave][c][0] = dbs[c];
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    float s = 0.f;
+    for (int w = 0; w < ROW_WAVES; ++w) s += red[w][threadIdx.x][0];
+    slab[(size_t)4 * D + threadIdx.x] = s;
+  }
+}
+
+// out[slot][e] = sum_blocks partial[block][slot][e]
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ partial, int nblocks, int nslots, int D,
+                                                          float* out0, float* out1, float* out2, float* out3, float* out4, int len4) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int slot = blockIdx.y;
+  float* outs[5] = {out0, out1, out2, out3, out4};
+  float* o = outs[slot];
+  if (!o) return;
+  const int len = (slot == 4) ? len4 : D;
+  if (e >= len) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partial[((size_t)b * nslots + slot) * D + e];
+  o[e] = s;
+}
+
+// dpos[pos_offset+i,:] += sum_b dpre[b,i,:]
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ dpre, int B, int L, int D, float* __restrict__ dpos, int pos_offset) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int per_row = D / 4;
+  if (idx >= (size_t)L * per_row) return;
+  const int i = (int)(idx / per_row), e = 4 * (int)(idx % per_row);
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < B; ++b) {
+    float v[4];
+    load4<T>(dpre + ((size_t)b * L + i) * D + e, v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] += v[j];
+  }
+  float* o = dpos + (size_t)(pos_offset + i) * D + e;
+  float cur[4];
+  load4<float>(o, cur);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) cur[j] += s[j];
+  store4<float>(o, cur);
+}
+// dtype0[e] += sum_i rowsums[i][e], rowsums = the rows of dpos just written minus their previous content is
+// not recoverable, so the sum is taken over dpre directly (second pass over L rows of per-position sums kept
+// in `scratch` [L, D]).
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_type_kernel(const T* __restrict__ dpre, int rows, int D, float* __restrict__ partial) {
+  // grid: (ceil(D/4/256), 64 row slices) -> partial[slice][D]
+  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= D) return;
+  const int per = (rows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int r = r0; r < r1; ++r) {
+    float v[4];
+    load4<T>(dpre + (size_t)r * D + e, v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] += v[j];
+  }
+  store4<float>(partial + (size_t)blockIdx.y * D + e, s);
+}
+__global__ __launch_bounds__(256) void embed_bwd_type_final(const float* __restrict__ partial, int nparts, int D, float* __restrict__ dtype0) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= D) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * D + e];
+  dtype0[e] += s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static inline int pick_nv(int D) {
+  const int need = ceil_div(D, 256);
+  if (need <= 1) return 1;
+  if (need <= 2) return 2;
+  if (need <= 4) return 4;
+  if (need <= 8) return 8;
+  if (need <= 16) return 16;
+  return 0;
+}
+
+template <typename F> static inline void dispatch_nv(int nv, F&& f) {
+  switch (nv) {
+    case 1: f(std::integral_constant<int, 1>{}); break;
+    case 2: f(std::integral_constant<int, 2>{}); break;
+    case 4: f(std::integral_constant<int, 4>{}); break;
+    case 8: f(std::integral_constant<int, 8>{}); break;
+    default: f(std::integral_constant<int, 16>{}); break;
+  }
+}
+template <typename F> static inline void dispatch_nv8(int nv, F&& f) {   // kernels that keep several rows of state: D <= 2048
+  switch (nv) {
+    case 1: f(std::integral_constant<int, 1>{}); break;
+    case 2: f(std::integral_constant<int, 2>{}); break;
+    case 4: f(std::integral_constant<int, 4>{}); break;
+    default: f(std::integral_constant<int, 8>{}); break;
+  }
+}
+
+template <typename T, bool EMBED>
+static int ln_fwd_launch(hipStream_t st, const void* x, const float* pos, int pos_offset, int L, const float* type0, const float* gamma,
+                         const float* beta, float eps, int rows, int D, void* y, void* pre, float* mean, float* rstd,
+                         const float* head_w, const float* head_b, int n_out, float* scores) {
+  const int nv = pick_nv(D);
+  MTS_UNSUPPORTED(nv > 0 && D % 4 == 0, "layernorm: D=%d must be a multiple of 4 and <= 4096", D);
+  dim3 grid(ceil_div(rows, ROW_WAVES)), block(64 * ROW_WAVES);
+  dispatch_nv(nv, [&](auto nvc) {
+    constexpr int NV = decltype(nvc)::value;
+    hipLaunchKernelGGL((ln_fwd_kernel<T, NV, EMBED>), grid, block, 0, st, x, pos, pos_offset, L, type0, gamma, beta, eps, rows, D, (T*)y,
+                       (T*)pre, mean, rstd, head_w, head_b, n_out, scores);
+  });
+  MTS_LAUNCH_CHECK("layernorm_fwd");
+  return MTS_OK;
+}
+
+extern "C" int mts_embed_layernorm_fwd(void* stream, int dtype, int B, int L, int D, const float* x, const float* pos, int pos_offset,
+                                       const float* type0, const float* gamma, const float* beta, float eps, void* y, void* pre,
+                                       float* mean, float* rstd) {
+  MTS_CHECK_ARG(B > 0 && L > 0 && D > 0 && x && pos && type0 && gamma && beta && y, "mts_embed_layernorm_fwd: bad arguments");
+  if (dtype == MTS_F32)
+    return ln_fwd_launch<float, true>((hipStream_t)stream, x, pos, pos_offset, L, type0, gamma, beta, eps, B * L, D, y, pre, mean, rstd,
+                                      nullptr, nullptr, 0, nullptr);
+  if (dtype == MTS_BF16)
+    return ln_fwd_launch<bf16_t, true>((hipStream_t)stream, x, pos, pos_offset, L, type0, gamma, beta, eps, B * L, D, y, pre, mean, rstd,
+                                       nullptr, nullptr, 0, nullptr);
+  mts_set_error("mts_embed_layernorm_fwd: bad dtype %d", dtype);
+  return MTS_ERR_INVALID;
+}
+
+extern "C" int mts_layernorm_fwd(void* stream, int dtype, int rows, int D, const void* x, const float* gamma, const float* beta, float eps,
+                                 void* y, float* mean, float* rstd, const float* head_w, const float* head_b, int n_out, float* scores) {
+  MTS_CHECK_ARG(rows > 0 && D > 0 && x && gamma && beta && y, "mts_layernorm_fwd: bad arguments");
+  MTS_CHECK_ARG(!head_w || (head_b && scores && n_out >= 1 && n_out <= 4), "mts_layernorm_fwd: fused head needs head_b, scores, n_out<=4");
+  if (dtype == MTS_F32)
+    return ln_fwd_launch<float, false>((hipStream_t)stream, x, nullptr, 0, 1, nullptr, gamma, beta, eps, rows, D, y, nullptr, mean, rstd,
+                                       head_w, head_b, n_out, scores);
+  if (dtype == MTS_BF16)
+    return ln_fwd_launch<bf16_t, false>((hipStream_t)stream, x, nullptr, 0, 1, nullptr, gamma, beta, eps, rows, D, y, nullptr, mean, rstd,
+                                        head_w, head_b, n_out, scores);
+  mts_set_error("mts_layernorm_fwd: bad dtype %d", dtype);
+  return MTS_ERR_INVALID;
+}
+
+extern "C" size_t mts_layernorm_bwd_workspace(int D) { return (size_t)BWD_MAX_BLOCKS * 5 * (size_t)D * sizeof(float); }
+
+template <typename T>
+static int ln_bwd_launch(hipStream_t st, int rows, int D, const void* x, const void* dy, const float* dlogit, const float* head_w, int n_out,
+                         const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, float* dxsum,
+                         void* partial) {
+  const int nv = pick_nv(D);
+  MTS_UNSUPPORTED(nv > 0 && nv <= 8 && D % 4 == 0, "layernorm_bwd: D=%d must be a multiple of 4 and <= 2048", D);
+  const int blocks = std::min(BWD_MAX_BLOCKS, ceil_div(rows, ROW_WAVES));
+  dispatch_nv8(nv, [&](auto nvc) {
+    constexpr int NV = decltype(nvc)::value;
+    hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), dim3(blocks), dim3(64 * ROW_WAVES), 0, st, (const T*)x, (const T*)dy, dlogit, head_w, n_out, gamma,
+                       mean, rstd, rows, D, (T*)dx, (float*)partial);
+  });
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(D, 256), 3), dim3(256), 0, st, (const float*)partial, blocks, 3, D, dgamma, dbeta,
+                     dxsum, (float*)nullptr, (float*)nullptr, 0);
+  MTS_LAUNCH_CHECK("layernorm_bwd");
+  return MTS_OK;
+}
+
+extern "C" int mts_layernorm_bwd(void* stream, int dtype, int rows, int D, const void* x, const void* dy, const float* dlogit,
+                                 const float* head_w, int n_out, const float* gamma, const float* mean, const float* rstd, void* dx,
+                                 float* dgamma, float* dbeta, float* dxsum, void* partial) {
+  MTS_CHECK_ARG(rows > 0 && D > 0 && x && gamma && mean && rstd && dx && partial, "mts_layernorm_bwd: bad arguments");
+  MTS_CHECK_ARG(dy || head_w, "mts_layernorm_bwd: needs dy and/or a fused head gradient");
+  MTS_CHECK_ARG(!head_w || (dlogit && n_out >= 1 && n_out <= 4), "mts_layernorm_bwd: fused head needs dlogit, n_out<=4");
+  if (dtype == MTS_F32)
+    return ln_bwd_launch<float>((hipStream_t)stream, rows, D, x, dy, dlogit, head_w, n_out, gamma, mean, rstd, dx, dgamma, dbeta, dxsum, partial);
+  if (dtype == MTS_BF16)
+    return ln_bwd_launch<bf16_t>((hipStream_t)stream, rows, D, x, dy, dlogit, head_w, n_out, gamma, mean, rstd, dx, dgamma, dbeta, dxsum, partial);
+  mts_set_error("mts_layernorm_bwd: bad dtype %d", dtype);
+  return MTS_ERR_INVALID;
+}
+
+extern "C" int mts_embed_bwd(void* stream, int dtype, int B, int L, int D, const void* dpre, float* dpos, int pos_offset, float* dtype0,
+                             void* partial) {
+  MTS_CHECK_ARG(B > 0 && L > 0 && D > 0 && D % 4 == 0 && dpre && dpos && dtype0 && partial, "mts_embed_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = (int)(((size_t)L * (D / 4) + 255) / 256);
+  const int slices = 64;
+  dim3 g2(ceil_div(D / 4, 256), slices);
+  if (dtype == MTS_F32) {
+    hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dpre, B, L, D, dpos, pos_offset);
+    hipLaunchKernelGGL(embed_bwd_type_kernel<float>, g2, dim3(256), 0, st, (const float*)dpre, B * L, D, (float*)partial);
+  } else if (dtype == MTS_BF16) {
+    hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dpre, B, L, D, dpos, pos_offset);
+    hipLaunchKernelGGL(embed_bwd_type_kernel<bf16_t>, g2, dim3(256), 0, st, (const bf16_t*)dpre, B * L, D, (float*)partial);
+  } else {
+    mts_set_error("mts_embed_bwd: bad dtype %d", dtype);
+    return MTS_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(embed_bwd_type_final, dim3(ceil_div(D, 256)), dim3(256), 0, st, (const float*)partial, slices, D, dtype0);
+  MTS_LAUNCH_CHECK("mts_embed_bwd");
+  return MTS_OK;
+}
+
+extern "C" int mts_head_fwd(void* stream, int dtype, int rows, int D, int n_out, const void* x, int ldx, const float* w, const float* b,
+                            float* scores) {
+  MTS_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && n_out >= 1 && n_out <= 4 && x && w && b && scores, "mts_head_fwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(ceil_div(rows, ROW_WAVES)), block(64 * ROW_WAVES);
+  if (dtype == MTS_F32) hipLaunchKernelGGL(head_fwd_kernel<float>, grid, block, 0, st, (const float*)x, ldx, rows, D, n_out, w, b, scores);
+  else if (dtype == MTS_BF16) hipLaunchKernelGGL(head_fwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, rows, D, n_out, w, b, scores);
+  else { mts_set_error("mts_head_fwd: bad dtype %d", dtype); return MTS_ERR_INVALID; }
+  MTS_LAUNCH_CHECK("mts_head_fwd");
+  return MTS_OK;
+}
+
+extern "C" int mts_head_bwd_params(void* stream, int dtype, int rows, int D, int n_out, const void* x, int ldx, const float* dscores,
+                                   float* dw, float* db, void* partial) {
+  MTS_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && n_out >= 1 && n_out <= 4 && x && dscores && dw && db && partial,
+                "mts_head_bwd_params: bad arguments");
+  const int nv = pick_nv(D);
+  MTS_UNSUPPORTED(nv > 0 && nv <= 8, "mts_head_bwd_params: D=%d must be <= 2048", D);
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = std::min(BWD_MAX_BLOCKS, ceil_div(rows, ROW_WAVES));
+  if (dtype == MTS_F32) {
+    dispatch_nv8(nv, [&](auto nvc) {
+      constexpr int NV = decltype(nvc)::value;
+      hipLaunchKernelGGL((head_bwd_params_kernel<float, NV>), dim3(blocks), dim3(64 * ROW_WAVES), 0, st, (const float*)x, ldx, dscores, n_out,
+                         rows, D, (float*)partial);
+    });
+  } else if (dtype == MTS_BF16) {
+    dispatch_nv8(nv, [&](auto nvc) {
+      constexpr int NV = decltype(nvc)::value;
+      hipLaunchKernelGGL((head_bwd_params_kernel<bf16_t, NV>), dim3(blocks), dim3(64 * ROW_WAVES), 0, st, (const bf16_t*)x, ldx, dscores, n_out,
+                         rows, D, (float*)partial);
+    });
+  } else { mts_set_error("mts_head_bwd_params: bad dtype %d", dtype); return MTS_ERR_INVALID; }
+  float* rowp[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int c = 0; c < n_out; ++c) rowp[c] = dw + (size_t)c * D;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(D, 256), 5), dim3(256), 0, st, (const float*)partial, blocks, 5, D, rowp[0], rowp[1],
+                     rowp[2], rowp[3], db, n_out);
+  MTS_LAUNCH_CHECK("mts_head_bwd_params");
+  return MTS_OK;
+}
+
+extern "C" int mts_head_bwd_data(void* stream, int dtype, int rows, int D, int n_out, const float* dscores, const float* w, void* dx, int lddx,
+                                 int accumulate) {
+  MTS_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && lddx % 4 == 0 && n_out >= 1 && n_out <= 4 && dscores && w && dx, "mts_head_bwd_data: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = (int)(((size_t)rows * (D / 4) + 255) / 256);
+  if (dtype == MTS_F32) hipLaunchKernelGGL(head_bwd_data_kernel<float>, dim3(blocks), dim3(256), 0, st, dscores, w, rows, D, n_out, (float*)dx, lddx, accumulate);
+  else if (dtype == MTS_BF16) hipLaunchKernelGGL(head_bwd_data_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, dscores, w, rows, D, n_out, (bf16_t*)dx, lddx, accumulate);
+  else { mts_set_error("mts_head_bwd_data: bad dtype %d", dtype); return MTS_ERR_INVALID; }
+  MTS_LAUNCH_CHECK("mts_head_bwd_data");
+  return MTS_OK;
+}
+
+// dx = dy * gelu'(u), in place on dy (FFN backward; modeling_longformer.py:1113-1116 uses erf-GELU)
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(size_t n, const T* __restrict__ u, T* __restrict__ dy) {
+  const size_t stride = (size_t)gridDim.x * 256 * 4;
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i + 3 < n; i += stride) {
+    float uv[4], dv[4];
+    load4<T>(u + i, uv); load4<T>(dy + i, dv);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dv[j] *= gelu_erf_grad_f(uv[j]);
+    store4<T>(dy + i, dv);
+  }
+}
+extern "C" int mts_gelu_bwd(void* stream, int dtype, size_t n, const void* u, void* dy) {
+  MTS_CHECK_ARG(u && dy && n % 4 == 0, "mts_gelu_bwd: bad arguments (n must be a multiple of 4)");
+  if (n == 0) return MTS_OK;
+  const int blocks = (int)std::min<size_t>(2048, (n / 4 + 255) / 256);
+  if (dtype == MTS_F32) hipLaunchKernelGGL(gelu_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, (const float*)u, (float*)dy);
+  else if (dtype == MTS_BF16) hipLaunchKernelGGL(gelu_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, (const bf16_t*)u, (bf16_t*)dy);
+  else { mts_set_error("mts_gelu_bwd: bad dtype %d", dtype); return MTS_ERR_INVALID; }
+  MTS_LAUNCH_CHECK("mts_gelu_bwd");
+  return MTS_OK;
+}

@@ -1,0 +1,187 @@
+"""Tensor-level wrappers over the C ABI (include/mts.h).  torch is used for device memory and streams only:
+every function enqueues hand-written HIP kernels on torch's current stream through raw device pointers.
+"""
+import math
+
+import torch
+
+from . import _lib as L
+from ._lib import check, lib, ptr, stream_ptr, dtype_code
+
+_ws_cache = {}
+
+
+def _scratch(nbytes, device, tag):
+    """Grow-only scratch buffers keyed by (device, tag): never reallocated inside a steady-state step."""
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def gemm(layout, A, B, out, *, M, N, K, lda=None, ldb=None, ldc=None, bias=None, residual=None, aux=None, gelu=False,
+         colscale=None, ncols_scaled=0, accumulate=False):
+    """C[M,N] = op(A) op(B) (+ epilogue).  A/B share a dtype (fp32 or bf16); out is fp32 or that dtype."""
+    a_dt = dtype_code(A.dtype)
+    assert B.dtype == A.dtype
+    c_dt = dtype_code(out.dtype)
+    epi = 0
+    if bias is not None:
+        epi |= L.EPI_BIAS
+    if residual is not None:
+        epi |= L.EPI_RESIDUAL
+    if gelu:
+        epi |= L.EPI_GELU
+    if colscale is not None:
+        epi |= L.EPI_COLSCALE
+    if accumulate:
+        epi |= L.EPI_ACCUM
+    lda = lda if lda is not None else A.stride(0)
+    ldb = ldb if ldb is not None else B.stride(0)
+    ldc = ldc if ldc is not None else out.stride(0)
+    check(lib.mts_gemm(stream_ptr(), a_dt, c_dt, layout, M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc, ptr(bias),
+                       ptr(residual), residual.stride(0) if residual is not None else 0, ptr(aux),
+                       aux.stride(0) if aux is not None else 0, epi, float(colscale or 1.0), int(ncols_scaled)))
+    return out
+
+
+def linear_fwd(x, w, b, out, **kw):
+    """out[M,N] = x[M,K] w[N,K]^T + b."""
+    return gemm(L.NT, x, w, out, M=x.shape[0], N=w.shape[0], K=x.shape[1], bias=b, **kw)
+
+
+def linear_dgrad(dy, w, out, **kw):
+    """out[M,K] = dy[M,N] w[N,K]."""
+    return gemm(L.NN, dy, w, out, M=dy.shape[0], N=w.shape[1], K=dy.shape[1], **kw)
+
+
+def linear_wgrad(dy, x, out, **kw):
+    """out[N,K] (fp32) = dy[M,N]^T x[M,K]."""
+    return gemm(L.TN, dy, x, out, M=dy.shape[1], N=x.shape[1], K=dy.shape[0], **kw)
+
+
+def colsum(x, out, accumulate=False):
+    M, N = x.shape
+    ws = _scratch(lib.mts_colsum_workspace(N), x.device, 'colsum')
+    check(lib.mts_colsum(stream_ptr(), dtype_code(x.dtype), M, N, ptr(x), x.stride(0), ptr(out), int(accumulate), ptr(ws)))
+    return out
+
+
+def cast(src, dst):
+    check(lib.mts_cast(stream_ptr(), dtype_code(dst.dtype), ptr(src), ptr(dst), src.numel()))
+    return dst
+
+
+def embed_layernorm_fwd(x, pos, pos_offset, type0, gamma, beta, eps, y, pre, mean, rstd):
+    B, Lq, D = x.shape
+    check(lib.mts_embed_layernorm_fwd(stream_ptr(), dtype_code(y.dtype), B, Lq, D, ptr(x), ptr(pos), pos_offset, ptr(type0),
+                                      ptr(gamma), ptr(beta), eps, ptr(y), ptr(pre), ptr(mean), ptr(rstd)))
+
+
+def layernorm_fwd(x, gamma, beta, eps, y, mean, rstd, head_w=None, head_b=None, scores=None):
+    rows, D = x.shape
+    n_out = head_w.shape[0] if head_w is not None else 0
+    check(lib.mts_layernorm_fwd(stream_ptr(), dtype_code(x.dtype), rows, D, ptr(x), ptr(gamma), ptr(beta), eps, ptr(y),
+                                ptr(mean), ptr(rstd), ptr(head_w), ptr(head_b), n_out, ptr(scores)))
+
+
+def layernorm_bwd(x, dy, gamma, mean, rstd, dx, dgamma, dbeta, dxsum=None, dlogit=None, head_w=None):
+    rows, D = x.shape
+    ws = _scratch(lib.mts_layernorm_bwd_workspace(D), x.device, 'ln_bwd')
+    n_out = head_w.shape[0] if head_w is not None else 0
+    check(lib.mts_layernorm_bwd(stream_ptr(), dtype_code(x.dtype), rows, D, ptr(x), ptr(dy), ptr(dlogit), ptr(head_w), n_out,
+                                ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(dxsum), ptr(ws)))
+
+
+def embed_bwd(dpre, B, Lq, dpos, pos_offset, dtype0):
+    D = dpre.shape[-1]
+    ws = _scratch(64 * D * 4, dpre.device, 'embed_bwd')
+    check(lib.mts_embed_bwd(stream_ptr(), dtype_code(dpre.dtype), B, Lq, D, ptr(dpre), ptr(dpos), pos_offset, ptr(dtype0), ptr(ws)))
+
+
+def gelu_bwd(u, dy):
+    check(lib.mts_gelu_bwd(stream_ptr(), dtype_code(u.dtype), u.numel(), ptr(u), ptr(dy)))
+
+
+def band_slots(radius):
+    return lib.mts_band_slots(radius)
+
+
+def band_attn_fwd(qkv, lengths, B, Lq, D, heads, radius, ctx, probs):
+    check(lib.mts_band_attn_fwd(stream_ptr(), dtype_code(qkv.dtype), B, Lq, D, heads, radius, ptr(qkv), ptr(lengths), ptr(ctx), ptr(probs)))
+
+
+def band_attn_bwd(qkv, lengths, probs, dctx, B, Lq, D, heads, radius, dqkv, dscores):
+    q_scale = 1.0 / math.sqrt(D // heads)
+    check(lib.mts_band_attn_bwd(stream_ptr(), dtype_code(qkv.dtype), B, Lq, D, heads, radius, q_scale, ptr(qkv), ptr(lengths),
+                                ptr(probs), ptr(dctx), ptr(dqkv), ptr(dscores)))
+
+
+def tagger_loss(kind, scores, targets, lengths, alpha, gamma, loss_out, dscores):
+    B, Lq, n_out = scores.shape
+    check(lib.mts_tagger_loss(stream_ptr(), kind, B, Lq, targets.shape[1], n_out, ptr(scores), ptr(targets), ptr(lengths),
+                              float(alpha), float(gamma), ptr(loss_out), ptr(dscores)))
+
+
+def greedy_decode(scores, lengths, threshold, tags_out):
+    B, Lq, n_out = scores.shape
+    check(lib.mts_greedy_decode(stream_ptr(), B, Lq, n_out, ptr(scores), ptr(lengths), float(threshold), ptr(tags_out)))
+
+
+def head_fwd(x, w, b, scores):
+    rows, D = x.shape
+    check(lib.mts_head_fwd(stream_ptr(), dtype_code(x.dtype), rows, D, w.shape[0], ptr(x), x.stride(0), ptr(w), ptr(b), ptr(scores)))
+
+
+def head_bwd_params(x, dscores, dw, db):
+    rows, D = x.shape
+    ws = _scratch(lib.mts_layernorm_bwd_workspace(D), x.device, 'ln_bwd')
+    check(lib.mts_head_bwd_params(stream_ptr(), dtype_code(x.dtype), rows, D, dw.shape[0], ptr(x), x.stride(0), ptr(dscores),
+                                  ptr(dw), ptr(db), ptr(ws)))
+
+
+def head_bwd_data(dscores, w, dx, accumulate=False):
+    rows, D = dx.shape
+    check(lib.mts_head_bwd_data(stream_ptr(), dtype_code(dx.dtype), rows, D, w.shape[0], ptr(dscores), ptr(w), ptr(dx),
+                                dx.stride(0), int(accumulate)))
+
+
+def lstm_workspace(dtype, B, Lq, H, ndir, device):
+    return _scratch(lib.mts_lstm_workspace(dtype_code(dtype), B, Lq, H, ndir), device, 'lstm')
+
+
+def lstm_fwd(xproj, w_hh, b_hh, lengths, B, Lq, H, ndir, out, gates, cells):
+    ws = lstm_workspace(xproj.dtype, B, Lq, H, ndir, xproj.device)
+    check(lib.mts_lstm_fwd(stream_ptr(), dtype_code(xproj.dtype), B, Lq, H, ndir, ptr(xproj), ptr(w_hh), ptr(b_hh), ptr(lengths), ptr(out),
+                           ptr(gates), ptr(cells), ptr(ws)))
+
+
+def lstm_bwd(w_hh, lengths, out, gates, cells, dout, B, Lq, H, ndir, dxproj, dw_hh):
+    ws = lstm_workspace(out.dtype, B, Lq, H, ndir, out.device)
+    check(lib.mts_lstm_bwd(stream_ptr(), dtype_code(out.dtype), B, Lq, H, ndir, ptr(w_hh), ptr(lengths), ptr(out), ptr(gates),
+                           ptr(cells), ptr(dout), ptr(dxproj), ptr(dw_hh), ptr(ws)))
+
+
+def crf_nll(feats, tags, lengths, trans, loss_out, dfeats=None, dtrans=None):
+    B, Lq, C = feats.shape
+    ws = _scratch(lib.mts_crf_workspace(B, Lq, C), feats.device, 'crf')
+    check(lib.mts_crf_nll(stream_ptr(), B, Lq, C, ptr(feats), ptr(tags), tags.shape[1], ptr(lengths), ptr(trans), ptr(loss_out),
+                          ptr(dfeats), ptr(dtrans), ptr(ws)))
+
+
+def crf_viterbi(feats, lengths, trans, best_score, paths):
+    B, Lq, C = feats.shape
+    ws = _scratch(B * Lq * C * 4, feats.device, 'crf_bp')
+    check(lib.mts_crf_viterbi(stream_ptr(), B, Lq, C, ptr(feats), ptr(lengths), ptr(trans), ptr(best_score), ptr(paths), ptr(ws)))
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale=1.0, bf16_copy=None):
+    check(lib.mts_adam_step(stream_ptr(), param.numel(), ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), lr, beta1, beta2,
+                            eps, step, grad_scale, ptr(bf16_copy)))
+
+
+def sgd_step(param, grad, buf, lr, momentum, weight_decay, first_step, grad_scale=1.0, bf16_copy=None):
+    check(lib.mts_sgd_step(stream_ptr(), param.numel(), ptr(param), ptr(grad), ptr(buf), lr, momentum, weight_decay,
+                           int(first_step), grad_scale, ptr(bf16_copy)))

@@ -1,0 +1,347 @@
+"""Recurrent taggers on the HIP kernels: BiLSTM, BiLSTMLateFusion, BiRnnCrf (see taggers.py for the contract).
+
+Reference: models/NeuralArchitectures.py:23-145 (RNN), models/CRF.py:274-369 (BiLSTM), :371-479 (BiLSTMLateFusion),
+:243-272 + :98-240 (BiRnnCrf + CRF; the reference wrapper unpacks a single tensor and crashes, SURVEY.md Q2 -- this
+one composes RNN -> CRF the way the reference evidently intended).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+from .flat import FlatLayout
+from .taggers import _TaggerBase, _linear_init, _xavier_uniform, LOSS_KINDS
+
+IMPOSSIBLE = -1e4   # models/CRF.py:95
+
+
+def _rnn_groups(prefix, D, H, num_layers, gen):
+    """Parameter groups + Keras-style init of ``RNN._reinitialize`` (NeuralArchitectures.py:58-79): xavier_uniform
+    W_ih, orthogonal W_hh, zero biases with the forget-gate slice of bias_ih set to 1.  The two directions of a
+    layer are adjacent so that one [8H, Din] GEMM projects both."""
+    groups, init = [], {}
+    for k in range(num_layers):
+        din = D if k == 0 else 2 * H
+        g = []
+        for sfx in ('', '_reverse'):
+            n = f'{prefix}rnn.weight_ih_l{k}{sfx}'
+            g.append((n, (4 * H, din)))
+            init[n] = _xavier_uniform((4 * H, din), gen)
+        groups.append(g)
+        g = []
+        for sfx in ('', '_reverse'):
+            n = f'{prefix}rnn.weight_hh_l{k}{sfx}'
+            g.append((n, (4 * H, H)))
+            w = torch.empty(4 * H, H)
+            nn.init.orthogonal_(w, generator=gen)
+            init[n] = w
+        groups.append(g)
+        for kind in ('bias_ih', 'bias_hh'):
+            g = []
+            for sfx in ('', '_reverse'):
+                n = f'{prefix}rnn.{kind}_l{k}{sfx}'
+                g.append((n, (4 * H,)))
+                b = torch.zeros(4 * H)
+                if kind == 'bias_ih':
+                    b[H:2 * H] = 1.0
+                init[n] = b
+            groups.append(g)
+    return groups, init
+
+
+class _RnnStack:
+    """Native forward/backward of one ``RNN`` (bidirectional multi-layer LSTM) living inside a flat-parameter model."""
+
+    def __init__(self, owner, prefix, D, H, num_layers, tag):
+        self.o, self.prefix, self.D, self.H, self.nl, self.tag = owner, prefix, D, H, num_layers, tag
+
+    def _names(self, kind, k):
+        return f'{self.prefix}rnn.{kind}_l{k}', f'{self.prefix}rnn.{kind}_l{k}_reverse'
+
+    def forward(self, x2d, lengths_i32, B, Lq):
+        """x2d: [B*Lq, D] in compute dtype.  Returns (out [N, 2H], saved state)."""
+        o, H = self.o, self.H
+        dt, dev = o.compute_dtype, x2d.device
+        N = B * Lq
+        wf, pf = o._weights(), o._flat
+        saved = []
+        h = x2d
+        for k in range(self.nl):
+            din = h.shape[1]
+            w_ih = o._wspan(wf, *self._names('weight_ih', k), 8 * H, din)
+            b_ih = o._wspan(pf, *self._names('bias_ih', k), 1, 8 * H).view(-1)
+            b_hh = o._wspan(pf, *self._names('bias_hh', k), 1, 8 * H).view(-1)
+            w_hh = o._wspan(pf, *self._names('weight_hh', k), 8 * H, H)
+            xproj = o._ws.get(f'{self.tag}xproj{k}', N, 8 * H, dt, dev)
+            ops.linear_fwd(h, w_ih, b_ih, xproj)
+            out = o._ws.get(f'{self.tag}out{k}', N, 2 * H, dt, dev)
+            gates = o._ws.get(f'{self.tag}gates{k}', N, 8 * H, dt, dev)
+            cells = o._ws.get(f'{self.tag}cells{k}', N, 2 * H, torch.float32, dev)
+            ops.lstm_fwd(xproj, w_hh, b_hh, lengths_i32, B, Lq, H, 2, out, gates, cells)
+            saved.append(dict(hin=h, out=out, gates=gates, cells=cells))
+            h = out
+        return h, saved
+
+    def backward(self, saved, dout, lengths_i32, B, Lq):
+        o, H = self.o, self.H
+        dt, dev = o.compute_dtype, dout.device
+        N = B * Lq
+        wf, pf, lay = o._weights(), o._flat, o._layout
+        g = o.grad_flat()
+        for k in range(self.nl - 1, -1, -1):
+            S = saved[k]
+            din = S['hin'].shape[1]
+            w_hh = o._wspan(pf, *self._names('weight_hh', k), 8 * H, H)
+            dxproj = o._ws.get(f'{self.tag}dxproj', N, 8 * H, dt, dev)
+            off, n = lay.span(*self._names('weight_hh', k))
+            ops.lstm_bwd(w_hh, lengths_i32, S['out'], S['gates'], S['cells'], dout, B, Lq, H, 2, dxproj, g[off:off + n])
+            off, n = lay.span(*self._names('bias_ih', k))
+            ops.colsum(dxproj, g[off:off + n])
+            off2, n2 = lay.span(*self._names('bias_hh', k))
+            g[off2:off2 + n2].copy_(g[off:off + n])
+            off, n = lay.span(*self._names('weight_ih', k))
+            ops.linear_wgrad(dxproj, S['hin'], g[off:off + n].view(8 * H, din))
+            if k > 0:
+                dprev = o._ws.get(f'{self.tag}dprev{k & 1}', N, din, dt, dev)
+                ops.linear_dgrad(dxproj, o._wspan(wf, *self._names('weight_ih', k), 8 * H, din), dprev)
+                dout = dprev
+
+
+class _RnnTaggerBase(_TaggerBase):
+    def _check_rnn_args(self, dropout_in, dropout_out, LSTM, bidirectional):
+        if dropout_in or dropout_out:
+            raise NotImplementedError('dropout > 0 is not implemented in the HIP LSTM path (note the reference applies '
+                                      'F.dropout even in eval mode, NeuralArchitectures.py:94; it tests with dropout 0)')
+        if not LSTM:
+            raise NotImplementedError('GRU (NeuralArchitectures.py:46-50) is listed as "next" in SURVEY.md §8f')
+        if not bidirectional:
+            raise NotImplementedError('unidirectional RNN (NeuralArchitectures.py:134-145) is listed as "next" in SURVEY.md §8f')
+
+    def _prep_input(self, xs, lengths):
+        """pad_packed_sequence semantics: the output covers max(lengths) positions (NeuralArchitectures.py:115)."""
+        B, Lin, _ = xs.shape
+        maxlen = int(lengths.max()) if lengths is not None else Lin
+        maxlen = min(maxlen, Lin)
+        x = xs[:, :maxlen].contiguous()
+        return x, maxlen
+
+    def _to_act(self, x):
+        x2 = x.reshape(-1, x.shape[-1])
+        if self.compute_dtype == torch.float32:
+            return x2.to(torch.float32).contiguous()
+        out = self._ws.get('xin_' + str(x2.shape[1]), x2.shape[0], x2.shape[1], torch.bfloat16, x.device)
+        ops.cast(x2.to(torch.float32).contiguous(), out)
+        return out
+
+
+class BiLSTM(_RnnTaggerBase):
+    """models/CRF.py:274-369."""
+
+    def __init__(self, tagset_size, embedding_dim, hidden_dim, num_layers=1, bidirectional=True, dropout_in=0.0, dropout_out=0.0,
+                 batch_first=True, LSTM=True, loss_fn='CrossEntropy', threshold=None, device=None, alpha=0.9, gamma=2,
+                 compute_dtype=None, seed=None):
+        super().__init__()
+        self._init_common(loss_fn, threshold, alpha, gamma, compute_dtype)
+        self._check_rnn_args(dropout_in, dropout_out, LSTM, bidirectional)
+        self.embedding_dim, self.hidden_dim, self.tagset_size, self.num_layers = embedding_dim, hidden_dim, tagset_size, num_layers
+        self.n_out = tagset_size if loss_fn == 'CrossEntropy' else 1
+        gen = torch.Generator().manual_seed(torch.initial_seed() if seed is None else seed)
+        groups, init = _rnn_groups('model.', embedding_dim, hidden_dim, num_layers, gen)
+        cw, cb = _linear_init(self.n_out, 2 * hidden_dim, gen)
+        groups.append([('classification.weight', (self.n_out, 2 * hidden_dim)), ('classification.bias', (self.n_out,))])
+        init['classification.weight'], init['classification.bias'] = cw, cb
+        self._init_flat(FlatLayout(groups), init)
+        self._rnn = _RnnStack(self, 'model.', embedding_dim, hidden_dim, num_layers, 'r')
+
+    def _fwd(self, xs, lengths):
+        x, Lq = self._prep_input(xs, lengths)
+        B = x.shape[0]
+        li32 = self._prep_lengths(lengths, B, Lq, xs.device)
+        h, saved = self._rnn.forward(self._to_act(x), li32, B, Lq)
+        scores = self._ws.get('scores', B * Lq, self.n_out, torch.float32, xs.device)
+        ops.head_fwd(h, self._w(self._flat, 'classification.weight'), self._w(self._flat, 'classification.bias'), scores)
+        return dict(B=B, L=Lq, li32=li32, h=h, saved=saved, scores=scores.view(B, Lq, self.n_out))
+
+    def loss_and_grad(self, xs, lengths, tags, want_grad=True):
+        L.require_gpu()
+        st = self._fwd(xs, lengths)
+        dev, B, Lq = xs.device, st['B'], st['L']
+        tg = tags.to(device=dev, dtype=torch.float32).contiguous()
+        if self.loss_kind == L.LOSS_CE and tg.shape[1] != Lq:
+            # the reference reshapes x [B*maxlen, 2] against tags [B*L] (CRF.py:354) and fails on a size mismatch
+            raise ValueError(f'Expected input batch_size ({B * Lq}) to match target batch_size ({tg.numel()}).')
+        loss_out = torch.empty(2, dtype=torch.float32, device=dev)
+        dsc = self._ws.get('dscores', B * Lq, self.n_out, torch.float32, dev) if want_grad else None
+        ops.tagger_loss(self.loss_kind, st['scores'], tg, st['li32'], self.alpha, self.gamma, loss_out, dsc)
+        if want_grad:
+            g, lay = self.grad_flat(), self._layout
+            ops.head_bwd_params(st['h'], dsc, lay.view(g, 'classification.weight'), lay.view(g, 'classification.bias'))
+            dout = self._ws.get('dout', B * Lq, 2 * self.hidden_dim, self.compute_dtype, dev)
+            ops.head_bwd_data(dsc, self._w(self._flat, 'classification.weight'), dout)
+            self._rnn.backward(st['saved'], dout, st['li32'], B, Lq)
+        return loss_out[0], st['scores']
+
+    def loss(self, xs, lengths, tags, segments=None):
+        """models/CRF.py:319-356 (segments / cosine auxiliary loss: SURVEY.md §8f 'next')."""
+        if segments is not None:
+            raise NotImplementedError('cosine auxiliary loss (models/CRF.py:23-92) is listed as "next" in SURVEY.md §8f')
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self._flat_params.values()):
+            return self._autograd_loss(lambda: self.loss_and_grad(xs, lengths, tags, True)[0])
+        return self.loss_and_grad(xs, lengths, tags, False)[0].clone()
+
+    def forward(self, xs, lenghts, threshold=0.4):
+        """models/CRF.py:358-369."""
+        L.require_gpu()
+        with torch.no_grad():
+            st = self._fwd(xs, lenghts)
+            scores = st['scores'].clone()
+            tags = self._decode(scores, st['li32'], lenghts, threshold)
+        return scores, tags
+
+
+class BiLSTMLateFusion(_RnnTaggerBase):
+    """models/CRF.py:371-479: two independent RNNs, plain concat (there is no gate in the reference), one head."""
+
+    def __init__(self, tagset_size, embedding_dim, hidden_dim, num_layers=1, bidirectional=True, dropout_in=0.0, dropout_out=0.0,
+                 batch_first=True, LSTM=True, loss_fn='CrossEntropy', threshold=None, device=None, alpha=0.9, gamma=2,
+                 compute_dtype=None, seed=None):
+        super().__init__()
+        self._init_common(loss_fn, threshold, alpha, gamma, compute_dtype)
+        self._check_rnn_args(dropout_in, dropout_out, LSTM, bidirectional)
+        self.embedding_dim, self.hidden_dim, self.tagset_size, self.num_layers = embedding_dim, hidden_dim, tagset_size, num_layers
+        self.n_out = tagset_size if loss_fn == 'CrossEntropy' else 1
+        gen = torch.Generator().manual_seed(torch.initial_seed() if seed is None else seed)
+        g1, i1 = _rnn_groups('model1.', embedding_dim[0], hidden_dim, num_layers, gen)
+        g2, i2 = _rnn_groups('model2.', embedding_dim[1], hidden_dim, num_layers, gen)
+        cw, cb = _linear_init(self.n_out, 4 * hidden_dim, gen)
+        groups = g1 + g2 + [[('classification.weight', (self.n_out, 4 * hidden_dim)), ('classification.bias', (self.n_out,))]]
+        init = {**i1, **i2, 'classification.weight': cw, 'classification.bias': cb}
+        self._init_flat(FlatLayout(groups), init)
+        self._rnn1 = _RnnStack(self, 'model1.', embedding_dim[0], hidden_dim, num_layers, 'r1')
+        self._rnn2 = _RnnStack(self, 'model2.', embedding_dim[1], hidden_dim, num_layers, 'r2')
+
+    def _fwd(self, x1, x2, lengths):
+        xa, Lq = self._prep_input(x1, lengths)
+        xb, _ = self._prep_input(x2, lengths)
+        B, H = xa.shape[0], self.hidden_dim
+        li32 = self._prep_lengths(lengths, B, Lq, x1.device)
+        h1, s1 = self._rnn1.forward(self._to_act(xa), li32, B, Lq)
+        h2, s2 = self._rnn2.forward(self._to_act(xb), li32, B, Lq)
+        cat = self._ws.get('cat', B * Lq, 4 * H, self.compute_dtype, x1.device)
+        cat[:, :2 * H].copy_(h1)                       # torch.cat((x1, x2), axis=2), models/CRF.py:425
+        cat[:, 2 * H:].copy_(h2)
+        scores = self._ws.get('scores', B * Lq, self.n_out, torch.float32, x1.device)
+        ops.head_fwd(cat, self._w(self._flat, 'classification.weight'), self._w(self._flat, 'classification.bias'), scores)
+        return dict(B=B, L=Lq, li32=li32, cat=cat, s1=s1, s2=s2, scores=scores.view(B, Lq, self.n_out))
+
+    def loss_and_grad(self, x1, x2, lengths, tags, want_grad=True):
+        L.require_gpu()
+        st = self._fwd(x1, x2, lengths)
+        dev, B, Lq, H = x1.device, st['B'], st['L'], self.hidden_dim
+        tg = tags.to(device=dev, dtype=torch.float32).contiguous()
+        loss_out = torch.empty(2, dtype=torch.float32, device=dev)
+        dsc = self._ws.get('dscores', B * Lq, self.n_out, torch.float32, dev) if want_grad else None
+        ops.tagger_loss(self.loss_kind, st['scores'], tg, st['li32'], self.alpha, self.gamma, loss_out, dsc)
+        if want_grad:
+            g, lay = self.grad_flat(), self._layout
+            ops.head_bwd_params(st['cat'], dsc, lay.view(g, 'classification.weight'), lay.view(g, 'classification.bias'))
+            dcat = self._ws.get('dcat', B * Lq, 4 * H, self.compute_dtype, dev)
+            ops.head_bwd_data(dsc, self._w(self._flat, 'classification.weight'), dcat)
+            d1 = self._ws.get('dout1', B * Lq, 2 * H, self.compute_dtype, dev)
+            d2 = self._ws.get('dout2', B * Lq, 2 * H, self.compute_dtype, dev)
+            d1.copy_(dcat[:, :2 * H])
+            d2.copy_(dcat[:, 2 * H:])
+            self._rnn1.backward(st['s1'], d1, st['li32'], B, Lq)
+            self._rnn2.backward(st['s2'], d2, st['li32'], B, Lq)
+        return loss_out[0], st['scores']
+
+    def loss(self, x1, x2, lengths, tags, segments=None):
+        """models/CRF.py:420-461."""
+        if segments is not None:
+            raise NotImplementedError('cosine auxiliary loss (models/CRF.py:23-92) is listed as "next" in SURVEY.md §8f')
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self._flat_params.values()):
+            return self._autograd_loss(lambda: self.loss_and_grad(x1, x2, lengths, tags, True)[0])
+        return self.loss_and_grad(x1, x2, lengths, tags, False)[0].clone()
+
+    def forward(self, x1, x2, lenghts, threshold=0.4):
+        """models/CRF.py:463-479."""
+        L.require_gpu()
+        with torch.no_grad():
+            st = self._fwd(x1, x2, lenghts)
+            scores = st['scores'].clone()
+            tags = self._decode(scores, st['li32'], lenghts, threshold)
+        return scores, tags
+
+
+class BiRnnCrf(_RnnTaggerBase):
+    """models/CRF.py:243-272 composed with CRF (:98-240): RNN -> fc(2H -> tags+2) -> CRF NLL / Viterbi."""
+
+    def __init__(self, tagset_size, embedding_dim, hidden_dim, num_layers=1, bidirectional=True, dropout_in=0.0, dropout_out=0.0,
+                 batch_first=True, LSTM=True, architecture='rnn', compute_dtype=None, seed=None):
+        super().__init__()
+        self._init_common('CrossEntropy', None, 0.9, 2, compute_dtype)
+        self._check_rnn_args(dropout_in, dropout_out, LSTM, bidirectional)
+        self.embedding_dim, self.hidden_dim, self.tagset_size, self.num_layers = embedding_dim, hidden_dim, tagset_size, num_layers
+        self.num_tags = tagset_size + 2                       # models/CRF.py:108-110
+        self.start_idx, self.stop_idx = self.num_tags - 2, self.num_tags - 1
+        if self.num_tags > 4:
+            raise NotImplementedError('CRF head supports tagset_size <= 2 (fused head kernels cover <= 4 outputs)')
+        gen = torch.Generator().manual_seed(torch.initial_seed() if seed is None else seed)
+        groups, init = _rnn_groups('model.', embedding_dim, hidden_dim, num_layers, gen)
+        C = self.num_tags
+        fw, fb = _linear_init(C, 2 * hidden_dim, gen)
+        trans = torch.randn(C, C, generator=gen)
+        trans[self.start_idx, :] = IMPOSSIBLE                 # models/CRF.py:115-117
+        trans[:, self.stop_idx] = IMPOSSIBLE
+        groups.append([('crf.fc.weight', (C, 2 * hidden_dim)), ('crf.fc.bias', (C,))])
+        groups.append([('crf.transitions', (C, C))])
+        init.update({'crf.fc.weight': fw, 'crf.fc.bias': fb, 'crf.transitions': trans})
+        self._init_flat(FlatLayout(groups), init)
+        self._rnn = _RnnStack(self, 'model.', embedding_dim, hidden_dim, num_layers, 'r')
+
+    def _fwd(self, xs, lengths):
+        x, Lq = self._prep_input(xs, lengths)
+        B = x.shape[0]
+        li32 = self._prep_lengths(lengths, B, Lq, xs.device)
+        h, saved = self._rnn.forward(self._to_act(x), li32, B, Lq)
+        feats = self._ws.get('feats', B * Lq, self.num_tags, torch.float32, xs.device)
+        ops.head_fwd(h, self._w(self._flat, 'crf.fc.weight'), self._w(self._flat, 'crf.fc.bias'), feats)
+        return dict(B=B, L=Lq, li32=li32, h=h, saved=saved, feats=feats.view(B, Lq, self.num_tags))
+
+    def loss_and_grad(self, xs, lengths, tags, want_grad=True):
+        L.require_gpu()
+        st = self._fwd(xs, lengths)
+        dev, B, Lq, C = xs.device, st['B'], st['L'], self.num_tags
+        tg = tags.to(device=dev, dtype=torch.float32).contiguous()
+        loss_out = torch.empty(2, dtype=torch.float32, device=dev)
+        g, lay = self.grad_flat(), self._layout
+        dfe = self._ws.get('dfeats', B * Lq, C, torch.float32, dev) if want_grad else None
+        ops.crf_nll(st['feats'], tg, st['li32'], self._w(self._flat, 'crf.transitions'), loss_out,
+                    dfe.view(B, Lq, C) if want_grad else None, lay.view(g, 'crf.transitions') if want_grad else None)
+        if want_grad:
+            ops.head_bwd_params(st['h'], dfe, lay.view(g, 'crf.fc.weight'), lay.view(g, 'crf.fc.bias'))
+            dout = self._ws.get('dout', B * Lq, 2 * self.hidden_dim, self.compute_dtype, dev)
+            ops.head_bwd_data(dfe, self._w(self._flat, 'crf.fc.weight'), dout)
+            self._rnn.backward(st['saved'], dout, st['li32'], B, Lq)
+        return loss_out[0], st['feats']
+
+    def loss(self, xs, lengths, tags):
+        """models/CRF.py:261-265."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self._flat_params.values()):
+            return self._autograd_loss(lambda: self.loss_and_grad(xs, lengths, tags, True)[0])
+        return self.loss_and_grad(xs, lengths, tags, False)[0].clone()
+
+    def forward(self, xs, lenghts):
+        """models/CRF.py:267-272 -> (best_score [B], best_paths list of int lists)."""
+        L.require_gpu()
+        with torch.no_grad():
+            st = self._fwd(xs, lenghts)
+            B, Lq = st['B'], st['L']
+            score = torch.empty(B, dtype=torch.float32, device=xs.device)
+            paths = torch.empty(B, Lq, dtype=torch.int32, device=xs.device)
+            ops.crf_viterbi(st['feats'], st['li32'], self._w(self._flat, 'crf.transitions'), score, paths)
+            ph = paths.cpu().numpy()
+            lens = [int(v) for v in (lenghts.tolist() if lenghts is not None else [Lq] * B)]
+        return score, [ph[i, :min(lens[i], Lq)].tolist() for i in range(B)]

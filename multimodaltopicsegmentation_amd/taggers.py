@@ -1,0 +1,409 @@
+"""Host-side mirror of the reference's tagger classes (models/CRF.py) on top of the HIP kernels.
+
+Same class names, constructor arguments, ``.loss(...)`` / ``.forward(...)`` contracts, ``.th`` attribute,
+error behaviour and ``state_dict`` keys as the reference:
+
+    Transformer_segmenter   models/CRF.py:508-610  (+ Longformer_Local_Attention, RestrictedTransformerLayer.py:65-133)
+    BiLSTM                  models/CRF.py:274-369  (+ RNN, NeuralArchitectures.py:23-145)
+    BiLSTMLateFusion        models/CRF.py:371-479
+    BiRnnCrf / CRF          models/CRF.py:243-272, :98-240   (the reference wrapper crashes; this one works)
+
+The arithmetic runs ONLY in libmts_hip.so (see include/mts.h); there is no PyTorch fallback.  Every model keeps
+its parameters in one flat fp32 buffer (flat.py) and has two front-ends over the same kernels:
+
+  * ``.loss()`` returns a 0-d tensor wired into autograd through a single custom Function (drop-in for
+    Lightning / torch optimizers: train_fit.py:300-335 works unchanged);
+  * ``.loss_and_grad()`` writes all gradients straight into the flat gradient buffer without autograd
+    (native trainer, bench.py, RCCL data parallel).
+"""
+import math
+import os
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+from .flat import FlatLayout, FlatModule
+
+LOSS_KINDS = {'CrossEntropy': L.LOSS_CE, 'BinaryCrossEntropy': L.LOSS_BCE, 'FocalLoss': L.LOSS_FOCAL}
+DEAD_HF_KEYS = ('word_embeddings', 'query_global', 'key_global', 'value_global', 'pooler', 'position_ids', 'token_type_ids')
+
+
+def default_compute_dtype():
+    v = os.environ.get('MTS_COMPUTE_DTYPE', 'fp32').lower()
+    return torch.bfloat16 if v in ('bf16', 'bfloat16') else torch.float32
+
+
+def _as_dtype(d):
+    if d is None:
+        return default_compute_dtype()
+    if isinstance(d, str):
+        return torch.bfloat16 if d.lower() in ('bf16', 'bfloat16') else torch.float32
+    return d
+
+
+def _xavier_uniform(shape, gen):
+    bound = math.sqrt(6.0 / (shape[0] + shape[1]))
+    return (torch.rand(shape, generator=gen) * 2 - 1) * bound
+
+
+def _linear_init(out_f, in_f, gen):
+    """nn.Linear default init (kaiming_uniform(a=sqrt(5)) -> U(-1/sqrt(in), 1/sqrt(in)) for weight and bias)."""
+    k = 1.0 / math.sqrt(in_f)
+    return (torch.rand(out_f, in_f, generator=gen) * 2 - 1) * k, (torch.rand(out_f, generator=gen) * 2 - 1) * k
+
+
+class _Workspace:
+    """Row-capacity-based activation buffers: allocated once for the largest B*L seen, sliced per batch."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, name, rows, cols, dtype, device):
+        key = name
+        t = self.bufs.get(key)
+        need = rows * cols
+        if t is None or t.numel() < need or t.dtype != dtype or t.device != device:
+            t = torch.empty(max(need, 1), dtype=dtype, device=device)
+            self.bufs[key] = t
+        return t[:need].view(rows, cols)
+
+
+class _TaggerBase(FlatModule):
+    """Shared tail: loss kinds, decode, autograd bridge, bf16 weight mirror."""
+
+    def _init_common(self, loss_fn, threshold, alpha, gamma, compute_dtype):
+        if loss_fn not in LOSS_KINDS:
+            raise ValueError('Choose one of CrossEntropy or BinaryCrossEntropy as loss function')   # models/CRF.py:312
+        self.loss_kind = LOSS_KINDS[loss_fn]
+        self.bce = loss_fn != 'CrossEntropy'
+        self.fl = loss_fn == 'FocalLoss'
+        self.alpha, self.gamma = float(alpha), float(gamma)
+        self.th = threshold
+        self.compute_dtype = _as_dtype(compute_dtype)
+        self._ws = _Workspace()
+        self._wcopy = None
+        self._wcopy_version = None
+        self.device = 'cuda' if torch.cuda.is_available() else 'cpu'   # models/CRF.py:283-286 (kept for API parity)
+
+    def _on_reflatten(self):
+        self._wcopy = None
+        self._wcopy_version = None
+
+    # ---- weights in compute precision ----------------------------------------------------------
+    def _weights(self):
+        """flat buffer in the compute dtype (bf16 mirror refreshed when the fp32 master changed)."""
+        if self.compute_dtype == torch.float32:
+            return self._flat
+        ver = self._flat._version
+        if self._wcopy is None or self._wcopy.device != self._flat.device:
+            self._wcopy = torch.empty(self._flat.numel(), dtype=torch.bfloat16, device=self._flat.device)
+            self._wcopy_version = None
+        if self._wcopy_version != ver:
+            ops.cast(self._flat, self._wcopy)
+            self._wcopy_version = ver
+        return self._wcopy
+
+    def mark_weights_synced(self):
+        """The fused optimizer wrote the bf16 mirror itself: skip the next cast."""
+        self._wcopy_version = self._flat._version
+
+    def _w(self, wflat, name):
+        return self._layout.view(wflat, name)
+
+    def _wspan(self, wflat, first, last, rows, cols):
+        off, n = self._layout.span(first, last)
+        return wflat[off:off + n].view(rows, cols)
+
+    @staticmethod
+    def _prep_lengths(lengths, B, L, device):
+        if lengths is None:
+            return torch.full((B,), L, dtype=torch.int32, device=device)
+        return lengths.to(device=device, dtype=torch.int32).contiguous()
+
+    # ---- decode (models/CRF.py:358-369) -----------------------------------------------------------
+    def _decode(self, scores, lengths_i32, lengths, threshold):
+        if self.th is not None:
+            threshold = self.th
+        B, Lq, _ = scores.shape
+        tags = torch.empty(B, Lq, dtype=torch.uint8, device=scores.device)
+        ops.greedy_decode(scores, lengths_i32, threshold, tags)
+        tags_h = tags.cpu().numpy().astype(bool)
+        lens = [int(v) for v in (lengths.tolist() if lengths is not None else [Lq] * B)]
+        return [tags_h[i, :lens[i]].tolist() for i in range(B)]
+
+    # ---- autograd bridge ---------------------------------------------------------------------------
+    def _autograd_loss(self, run_fwd_bwd):
+        """run_fwd_bwd() must run forward+backward natively, fill grad_flat and return the loss tensor (0-d)."""
+        params = list(self._flat_params.values())
+        return _NativeLoss.apply(self, run_fwd_bwd, *params)
+
+
+class _NativeLoss(torch.autograd.Function):
+    """One autograd node for the whole tagger: forward runs the native forward AND backward (activations never
+    leave the workspace), backward hands the flat gradient slices to autograd scaled by the incoming grad."""
+
+    @staticmethod
+    def forward(ctx, model, run, *params):
+        loss = run()
+        ctx.model = model
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        views = ctx.model.grad_views()
+        grads = [(v * gout).clone() for v in views.values()]
+        return (None, None, *grads)
+
+
+# =====================================================================================================
+# Restricted-window transformer tagger
+# =====================================================================================================
+class Transformer_segmenter(_TaggerBase):
+    """models/CRF.py:508-610 with restricted=True: HF-Longformer-style local attention encoder + linear head."""
+
+    def __init__(self, tagset_size, embedding_dim, hidden_dim, num_layers=6, nheads=8, dropout_in=0.0, dropout_out=0.0,
+                 batch_first=True, loss_fn='CrossEntropy', positional_encoding=True, threshold=None, restricted=True,
+                 window_size=127, alpha=0.9, gamma=2, compute_dtype=None, max_position_embedding=4096, seed=None):
+        super().__init__()
+        self._init_common(loss_fn, threshold, alpha, gamma, compute_dtype)
+        if not restricted:
+            raise NotImplementedError('restricted=False (HF BertModel full attention, models/CRF.py:544) is outside the hot path')
+        if dropout_in or dropout_out:
+            raise NotImplementedError('dropout > 0 is not implemented in the HIP encoder yet (the reference evaluates with '
+                                      'dropout 0, train_fit.py:360-361)')
+        self.embedding_dim, self.hidden_dim, self.tagset_size = embedding_dim, hidden_dim, tagset_size
+        self.nheads, self.num_layers = nheads, num_layers
+        # pyramidal windows, models/CRF.py:529; every entry must be even, RestrictedTransformerLayer.py:77-80
+        windows = [k * window_size for k in range(num_layers, 0, -1)]
+        assert all(w % 2 == 0 for w in windows), 'All window sizes must be divisible by 2!'
+        self.radii = [w // 2 for w in windows]            # one-sided radius, modeling_longformer.py:478
+        if embedding_dim % nheads != 0:
+            raise ValueError(f'The hidden size ({embedding_dim}) is not a multiple of the number of attention heads ({nheads})')
+        self.n_out = tagset_size if loss_fn == 'CrossEntropy' else 1
+        self.ln_eps = 1e-12                                # HF default; the wrapper's layer_norm_eps is ignored
+        self.max_pos = max_position_embedding
+        D, F = embedding_dim, hidden_dim
+
+        gen = torch.Generator().manual_seed(torch.initial_seed() if seed is None else seed)
+        std = 0.02                                         # HF initializer_range
+        groups, init = [], {}
+
+        def add(group, name, shape, value):
+            group.append((name, shape))
+            init[name] = value
+
+        e = 'model.model.embeddings.'
+        g = []
+        pos = torch.randn(self.max_pos, D, generator=gen) * std
+        pos[1].zero_()                                     # padding_idx = 1
+        add(g, e + 'position_embeddings.weight', (self.max_pos, D), pos)
+        groups.append(g)
+        g = []
+        add(g, e + 'token_type_embeddings.weight', (2, D), torch.randn(2, D, generator=gen) * std)
+        add(g, e + 'LayerNorm.weight', (D,), torch.ones(D))
+        add(g, e + 'LayerNorm.bias', (D,), torch.zeros(D))
+        groups.append(g)
+        for li in range(num_layers):
+            lp = f'model.model.encoder.layer.{li}.'
+            g = []
+            for n in ('query', 'key', 'value'):            # contiguous -> one [3D, D] GEMM operand
+                add(g, lp + f'attention.self.{n}.weight', (D, D), torch.randn(D, D, generator=gen) * std)
+            groups.append(g)
+            g = []
+            for n in ('query', 'key', 'value'):
+                add(g, lp + f'attention.self.{n}.bias', (D,), torch.zeros(D))
+            groups.append(g)
+            for name, shape, val in (
+                    ('attention.output.dense.weight', (D, D), torch.randn(D, D, generator=gen) * std),
+                    ('attention.output.dense.bias', (D,), torch.zeros(D)),
+                    ('attention.output.LayerNorm.weight', (D,), torch.ones(D)),
+                    ('attention.output.LayerNorm.bias', (D,), torch.zeros(D)),
+                    ('intermediate.dense.weight', (F, D), torch.randn(F, D, generator=gen) * std),
+                    ('intermediate.dense.bias', (F,), torch.zeros(F)),
+                    ('output.dense.weight', (D, F), torch.randn(D, F, generator=gen) * std),
+                    ('output.dense.bias', (D,), torch.zeros(D)),
+                    ('output.LayerNorm.weight', (D,), torch.ones(D)),
+                    ('output.LayerNorm.bias', (D,), torch.zeros(D))):
+                g = []
+                add(g, lp + name, shape, val)
+                groups.append(g)
+        cw, cb = _linear_init(self.n_out, D, gen)
+        g = []
+        add(g, 'classification.weight', (self.n_out, D), cw)
+        add(g, 'classification.bias', (self.n_out,), cb)
+        groups.append(g)
+        self._init_flat(FlatLayout(groups), init)
+        self._register_load_state_dict_pre_hook(self._drop_dead_keys)
+
+    @staticmethod
+    def _drop_dead_keys(state_dict, prefix, *args):
+        """A reference checkpoint carries ~68 M parameters the local-attention path never touches (HF word
+        embeddings, global-attention projections, pooler): ignore them on load."""
+        for k in [k for k in state_dict if k.startswith(prefix) and any(d in k for d in DEAD_HF_KEYS)]:
+            del state_dict[k]
+
+    # ---- native forward / backward ------------------------------------------------------------------
+    def _forward_native(self, xs, lengths_i32, want_grad_state=True):
+        dt, dev = self.compute_dtype, xs.device
+        B, Lq, D = xs.shape
+        if D != self.embedding_dim:
+            raise ValueError(f'expected input dim {self.embedding_dim}, got {D}')
+        if Lq + 2 > self.max_pos:
+            raise ValueError(f'sequence length {Lq} exceeds max_position_embeddings-2 = {self.max_pos - 2}')
+        N, F, H = B * Lq, self.hidden_dim, self.nheads
+        ws, lay = self._ws, self._layout
+        wf = self._weights()                  # compute-dtype mirror (GEMM operands)
+        pf = self._flat                       # fp32 masters (biases, LayerNorm, embeddings, head)
+        x = xs.contiguous().to(torch.float32)
+        e = 'model.model.embeddings.'
+        st = {'B': B, 'L': Lq, 'N': N, 'lengths': lengths_i32, 'layers': []}
+        h = ws.get('h0', N, D, dt, dev)
+        pre0 = ws.get('pre0', N, D, dt, dev)
+        mean0 = ws.get('mean0', N, 1, torch.float32, dev)
+        rstd0 = ws.get('rstd0', N, 1, torch.float32, dev)
+        ops.embed_layernorm_fwd(x, lay.view(pf, e + 'position_embeddings.weight'), 2,
+                                lay.view(pf, e + 'token_type_embeddings.weight')[0], lay.view(pf, e + 'LayerNorm.weight'),
+                                lay.view(pf, e + 'LayerNorm.bias'), self.ln_eps, h, pre0, mean0, rstd0)
+        st.update(pre0=pre0, mean0=mean0, rstd0=rstd0)
+        scores = ws.get('scores', N, self.n_out, torch.float32, dev)
+        scale = 1.0 / math.sqrt(D // H)
+        for li, radius in enumerate(self.radii):
+            lp = f'model.model.encoder.layer.{li}.'
+            slots = ops.band_slots(radius)
+            a_ = lp + 'attention.self.'
+            wqkv = self._wspan(wf, a_ + 'query.weight', a_ + 'value.weight', 3 * D, D)
+            bqkv = self._wspan(pf, a_ + 'query.bias', a_ + 'value.bias', 1, 3 * D).view(-1)
+            qkv = ws.get(f'qkv{li}', N, 3 * D, dt, dev)
+            ops.linear_fwd(h, wqkv, bqkv, qkv, colscale=scale, ncols_scaled=D)
+            ctx = ws.get(f'ctx{li}', N, D, dt, dev)
+            probs = ws.get(f'probs{li}', N, H * slots, torch.float32, dev)
+            ops.band_attn_fwd(qkv, lengths_i32, B, Lq, D, H, radius, ctx, probs)
+            s1 = ws.get(f's1_{li}', N, D, dt, dev)
+            ops.linear_fwd(ctx, self._w(wf, lp + 'attention.output.dense.weight'), self._w(pf, lp + 'attention.output.dense.bias'),
+                           s1, residual=h)
+            a1 = ws.get(f'a1_{li}', N, D, dt, dev)
+            mean1 = ws.get(f'mean1_{li}', N, 1, torch.float32, dev)
+            rstd1 = ws.get(f'rstd1_{li}', N, 1, torch.float32, dev)
+            ops.layernorm_fwd(s1, self._w(pf, lp + 'attention.output.LayerNorm.weight'),
+                              self._w(pf, lp + 'attention.output.LayerNorm.bias'), self.ln_eps, a1, mean1, rstd1)
+            u = ws.get(f'u{li}', N, F, dt, dev)
+            f = ws.get(f'f{li}', N, F, dt, dev)
+            ops.linear_fwd(a1, self._w(wf, lp + 'intermediate.dense.weight'), self._w(pf, lp + 'intermediate.dense.bias'), f,
+                           gelu=True, aux=u)
+            s2 = ws.get(f's2_{li}', N, D, dt, dev)
+            ops.linear_fwd(f, self._w(wf, lp + 'output.dense.weight'), self._w(pf, lp + 'output.dense.bias'), s2, residual=a1)
+            hout = ws.get(f'hout{li}', N, D, dt, dev)
+            mean2 = ws.get(f'mean2_{li}', N, 1, torch.float32, dev)
+            rstd2 = ws.get(f'rstd2_{li}', N, 1, torch.float32, dev)
+            last = li == len(self.radii) - 1
+            ops.layernorm_fwd(s2, self._w(pf, lp + 'output.LayerNorm.weight'), self._w(pf, lp + 'output.LayerNorm.bias'),
+                              self.ln_eps, hout, mean2, rstd2,
+                              head_w=self._w(pf, 'classification.weight') if last else None,
+                              head_b=self._w(pf, 'classification.bias') if last else None, scores=scores if last else None)
+            st['layers'].append(dict(hin=h, qkv=qkv, ctx=ctx, probs=probs, s1=s1, a1=a1, mean1=mean1, rstd1=rstd1, u=u, f=f,
+                                     s2=s2, hout=hout, mean2=mean2, rstd2=rstd2, radius=radius, slots=slots))
+            h = hout
+        st['scores'] = scores.view(B, Lq, self.n_out)
+        st['hidden'] = h
+        return st
+
+    def _backward_native(self, st, dscores):
+        """Fill grad_flat from the saved forward state; dscores fp32 [N, n_out]."""
+        dt = self.compute_dtype
+        B, Lq, N = st['B'], st['L'], st['N']
+        D, F, H = self.embedding_dim, self.hidden_dim, self.nheads
+        dev = dscores.device
+        ws, lay = self._ws, self._layout
+        wf, pf = self._weights(), self._flat
+        g = self.grad_flat()
+        G = lambda name: lay.view(g, name)
+        nl = len(self.radii)
+        dh = None
+        for li in range(nl - 1, -1, -1):
+            lp = f'model.model.encoder.layer.{li}.'
+            S = st['layers'][li]
+            last = li == nl - 1
+            ds2 = ws.get('ds2', N, D, dt, dev)
+            if last:
+                ops.head_bwd_params(S['hout'], dscores, G('classification.weight'), G('classification.bias'))
+            ops.layernorm_bwd(S['s2'], dh, self._w(pf, lp + 'output.LayerNorm.weight'), S['mean2'], S['rstd2'], ds2,
+                              G(lp + 'output.LayerNorm.weight'), G(lp + 'output.LayerNorm.bias'), dxsum=G(lp + 'output.dense.bias'),
+                              dlogit=dscores if last else None, head_w=self._w(pf, 'classification.weight') if last else None)
+            # FFN down:  s2 = f W2^T + b2 + a1
+            ops.linear_wgrad(ds2, S['f'], G(lp + 'output.dense.weight'))
+            du = ws.get('du', N, F, dt, dev)
+            ops.linear_dgrad(ds2, self._w(wf, lp + 'output.dense.weight'), du)
+            ops.gelu_bwd(S['u'], du)
+            ops.colsum(du, G(lp + 'intermediate.dense.bias'))
+            # FFN up:  u = a1 W1^T + b1 ;  da1 = ds2 (residual) + du W1
+            ops.linear_wgrad(du, S['a1'], G(lp + 'intermediate.dense.weight'))
+            da1 = ws.get('da1', N, D, dt, dev)
+            ops.linear_dgrad(du, self._w(wf, lp + 'intermediate.dense.weight'), da1, residual=ds2)
+            ds1 = ws.get('ds1', N, D, dt, dev)
+            ops.layernorm_bwd(S['s1'], da1, self._w(pf, lp + 'attention.output.LayerNorm.weight'), S['mean1'], S['rstd1'], ds1,
+                              G(lp + 'attention.output.LayerNorm.weight'), G(lp + 'attention.output.LayerNorm.bias'),
+                              dxsum=G(lp + 'attention.output.dense.bias'))
+            # attention output projection: s1 = ctx Wo^T + bo + hin
+            ops.linear_wgrad(ds1, S['ctx'], G(lp + 'attention.output.dense.weight'))
+            dctx = ws.get('dctx', N, D, dt, dev)
+            ops.linear_dgrad(ds1, self._w(wf, lp + 'attention.output.dense.weight'), dctx)
+            dqkv = ws.get('dqkv', N, 3 * D, dt, dev)
+            dsc = ws.get('dsc', N, H * S['slots'], torch.float32, dev)
+            ops.band_attn_bwd(S['qkv'], st['lengths'], S['probs'], dctx, B, Lq, D, H, S['radius'], dqkv, dsc)
+            a_ = lp + 'attention.self.'
+            off, n = lay.span(a_ + 'query.bias', a_ + 'value.bias')
+            ops.colsum(dqkv, g[off:off + n])
+            off, n = lay.span(a_ + 'query.weight', a_ + 'value.weight')
+            ops.linear_wgrad(dqkv, S['hin'], g[off:off + n].view(3 * D, D))
+            dhin = ws.get(f'dhin{li & 1}', N, D, dt, dev)
+            ops.linear_dgrad(dqkv, self._wspan(wf, a_ + 'query.weight', a_ + 'value.weight', 3 * D, D), dhin, residual=ds1)
+            dh = dhin
+        e = 'model.model.embeddings.'
+        dpre = ws.get('ds2', N, D, dt, dev)
+        ops.layernorm_bwd(st['pre0'], dh, self._w(pf, e + 'LayerNorm.weight'), st['mean0'], st['rstd0'], dpre,
+                          G(e + 'LayerNorm.weight'), G(e + 'LayerNorm.bias'))
+        G(e + 'position_embeddings.weight').zero_()
+        G(e + 'token_type_embeddings.weight').zero_()
+        ops.embed_bwd(dpre, B, Lq, G(e + 'position_embeddings.weight'), 2, G(e + 'token_type_embeddings.weight')[0])
+
+    # ---- public API ------------------------------------------------------------------------------------
+    def loss_and_grad(self, xs, lengths, tags, want_grad=True):
+        """Native forward(+backward): returns (loss 0-d fp32 tensor, scores [B,L,n_out]); gradients land in grad_flat."""
+        L.require_gpu()
+        dev = xs.device
+        B, Lq, _ = xs.shape
+        li32 = self._prep_lengths(lengths, B, Lq, dev)
+        st = self._forward_native(xs, li32)
+        tg = tags.to(device=dev, dtype=torch.float32).contiguous()
+        loss_out = torch.empty(2, dtype=torch.float32, device=dev)
+        dsc = self._ws.get('dscores', st['N'], self.n_out, torch.float32, dev) if want_grad else None
+        ops.tagger_loss(self.loss_kind, st['scores'], tg, li32, self.alpha, self.gamma, loss_out, dsc)
+        if want_grad:
+            self._backward_native(st, dsc)
+        return loss_out[0], st['scores']
+
+    def loss(self, xs, lengths, tags):
+        """models/CRF.py:574-595."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self._flat_params.values()):
+            return self._autograd_loss(lambda: self.loss_and_grad(xs, lengths, tags, True)[0])
+        return self.loss_and_grad(xs, lengths, tags, False)[0].clone()
+
+    def encode(self, xs, lengths):
+        """Encoder output [B, L, D] (``Longformer_Local_Attention.forward``, RestrictedTransformerLayer.py:118-133)."""
+        B, Lq, _ = xs.shape
+        st = self._forward_native(xs, self._prep_lengths(lengths, B, Lq, xs.device))
+        return st['hidden'].view(B, Lq, -1).to(torch.float32)
+
+    def forward(self, xs, lenghts, threshold=0.4):
+        """models/CRF.py:597-610 -> (scores [B,L,n_out], list of per-document bool lists)."""
+        L.require_gpu()
+        B, Lq, _ = xs.shape
+        li32 = self._prep_lengths(lenghts, B, Lq, xs.device)
+        with torch.no_grad():
+            st = self._forward_native(xs, li32)
+            scores = st['scores'].clone()
+            tags = self._decode(scores, li32, lenghts, threshold)
+        return scores, tags

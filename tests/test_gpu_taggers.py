@@ -1,0 +1,276 @@
+"""Model-level parity on a real MI355X against the fixtures recorded from the reference (tests/golden/*.npz):
+scores, loss, every gradient, greedy-decode boundary lists (bit-exact) -- through the public drop-in API
+(TextSegmenter / taggers), i.e. through the C ABI.
+
+fp32 mode ("parity mode") is held to ~1e-5; bf16 mode to a stated, looser tolerance (logits 5e-2 abs, loss 2e-2 rel)
+and boundary lists are required to agree wherever the reference probability is at least 0.02 away from the threshold.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _load_into(model, weights):
+    sd = model.state_dict()
+    missing = [k for k in sd if k not in weights]
+    assert not missing, missing
+    model.load_state_dict({k: torch.from_numpy(np.asarray(weights[k])) for k in sd})
+    return model.to(DEV)
+
+
+def _check_grads(model, ref_grads, rtol, atol, skip=()):
+    for n, p in model.named_parameters():
+        if n not in ref_grads or any(s in n for s in skip):
+            continue
+        got = p.grad.detach().float().cpu().numpy()
+        ref = ref_grads[n]
+        if got.shape != ref.shape:
+            got = got[: ref.shape[0]]
+        err = np.abs(got - ref)
+        lim = atol + rtol * np.abs(ref)
+        assert (err <= lim).all(), f'{n}: max err {err.max():.3e} vs ref max {np.abs(ref).max():.3e}'
+
+
+def _margin_equal(got_tags, ref_tags, ref_scores, lengths, th, margin, bce=True):
+    """bf16 mode: boundaries must agree except where the reference probability is within `margin` of the threshold."""
+    for b, n in enumerate(lengths):
+        s = torch.from_numpy(ref_scores[b, :n])
+        prob = torch.sigmoid(s[:, 0]) if bce else torch.softmax(s, -1)[:, 1]
+        for i in range(n):
+            if abs(float(prob[i]) - th) >= margin:
+                assert got_tags[b][i] == ref_tags[b][i], (b, i, float(prob[i]))
+
+
+# ------------------------------------------------------------------------------------------------ Transformer (a9, a10)
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('name,loss_fn', [('g3a_transformer_w4x2', 'FocalLoss'), ('g3b_transformer_w30', 'BinaryCrossEntropy'),
+                                          ('g3c_transformer_ce', 'CrossEntropy')])
+def test_transformer_small(name, loss_fn, dtype):
+    from multimodaltopicsegmentation_amd import TextSegmenter
+    g = H.load(name)
+    D, heads, ff, NL, window = [int(v) for v in g['cfg']]
+    n_out = 2 if loss_fn == 'CrossEntropy' else 1
+    ts = TextSegmenter(2, D, ff, num_layers=NL, architecture='Transformer', loss_fn=loss_fn, nheads=heads, attention_window=window,
+                       compute_dtype=dtype)
+    w = {k: H.seeded_param(k, shp, int(g['seed'])) for k, shp in H.band_param_shapes(D, ff, NL, n_out).items()}
+    m = _load_into(ts.model, w)
+    x, lengths, tags = torch.from_numpy(g['x']).to(DEV), torch.from_numpy(g['lengths']), torch.from_numpy(g['tags']).to(DEV)
+    lens = g['lengths'].tolist()
+    f32 = dtype == 'fp32'
+    hidden = m.encode(x, lengths)
+    np.testing.assert_allclose(hidden.cpu().numpy(), g['hidden'], atol=2e-5 if f32 else 6e-2, rtol=0)     # incl. padded rows
+    loss = m.loss(x, lengths, tags)
+    loss.backward()
+    assert abs(loss.item() - float(g['loss'])) < (2e-6 if f32 else 2e-2) * max(1.0, abs(float(g['loss'])))
+    ref_g = {k[2:]: v for k, v in g.items() if k.startswith('g.')}
+    _check_grads(m, ref_g, rtol=2e-3 if f32 else 8e-2, atol=2e-6 if f32 else 3e-3, skip=() if f32 else ('key.bias',))
+    for th in (0.4, 0.5):
+        m.th = th
+        scores, got = m(x, lengths)
+        ref_tags = H.split_tags(g[f'tags{th}'], lens)
+        if f32:
+            np.testing.assert_allclose(scores.cpu().numpy(), g['scores'], atol=2e-5, rtol=0)
+            assert got == ref_tags                                   # bit-exact boundary lists
+        else:
+            np.testing.assert_allclose(scores.cpu().numpy(), g['scores'], atol=5e-2, rtol=0)
+            _margin_equal(got, ref_tags, g['scores'], lens, th, 0.02, bce=n_out == 1)
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_transformer_1792(dtype):
+    """d=1792, 8 heads (hd 224), ff 256, one-sided window 15: the BASELINE config's layer at B=2, L=256."""
+    from multimodaltopicsegmentation_amd import TextSegmenter
+    g = H.load('g4_transformer_1792')
+    D, heads, ff, NL, window = [int(v) for v in g['cfg']]
+    ts = TextSegmenter(2, D, ff, num_layers=NL, architecture='Transformer', loss_fn='FocalLoss', nheads=heads, attention_window=window,
+                       compute_dtype=dtype)
+    w = {k: H.seeded_param(k, shp, int(g['seed'])) for k, shp in H.band_param_shapes(D, ff, NL, 1).items()}
+    m = _load_into(ts.model, w)
+    x = torch.from_numpy(g['x'].astype(np.float32)).to(DEV)
+    lengths, tags = torch.from_numpy(g['lengths']), torch.from_numpy(g['tags']).to(DEV)
+    lens = g['lengths'].tolist()
+    f32 = dtype == 'fp32'
+    loss = m.loss(x, lengths, tags)
+    loss.backward()
+    assert abs(loss.item() - float(g['loss'])) < (5e-6 if f32 else 2e-2) * max(1.0, abs(float(g['loss'])))
+    m.th = 0.5
+    scores, got = m(x, lengths)
+    ref_tags = H.split_tags(g['tags0.5'], lens)
+    np.testing.assert_allclose(scores.cpu().numpy(), g['scores'], atol=5e-5 if f32 else 8e-2, rtol=0)
+    if f32:
+        assert got == ref_tags
+    else:
+        _margin_equal(got, ref_tags, g['scores'], lens, 0.5, 0.03)
+    L = x.shape[1]
+    for n, p in m.named_parameters():
+        if 'ghead.' + n not in g or 'key.bias' in n:
+            continue
+        got_g = p.grad.detach().float().cpu().numpy()
+        if 'position_embeddings' in n:
+            assert np.all(got_g[L + 2:] == 0) and np.all(got_g[:2] == 0)
+            got_g = got_g[: L + 2]
+        ref_head, ref_sum = g['ghead.' + n], g['gsum.' + n]
+        scale = max(np.abs(ref_head).max(), 1e-6)
+        np.testing.assert_allclose(got_g.ravel()[:32], ref_head, rtol=5e-3 if f32 else 0.15, atol=(2e-4 if f32 else 4e-2) * scale, err_msg=n)
+        np.testing.assert_allclose(H.checksum(got_g)[1:], ref_sum[1:], rtol=2e-3 if f32 else 5e-2, err_msg=n)
+
+
+# ------------------------------------------------------------------------------------------------ BiLSTM (a4-a7)
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('tag,loss_fn', [('Fo', 'FocalLoss'), ('Bi', 'BinaryCrossEntropy'), ('Cr', 'CrossEntropy')])
+def test_bilstm_small(tag, loss_fn, dtype):
+    from multimodaltopicsegmentation_amd import TextSegmenter
+    g = H.load('g1_bilstm_small')
+    D, Hd, NL = [int(v) for v in g['cfg']]
+    ts = TextSegmenter(2, D, Hd, num_layers=NL, architecture='BiLSTM', loss_fn=loss_fn, compute_dtype=dtype)
+    m = _load_into(ts.model, {k[len(tag) + 3:]: v for k, v in g.items() if k.startswith(tag + '.w.')})
+    x, lengths, tags = torch.from_numpy(g['x']).to(DEV), torch.from_numpy(g['lengths']), torch.from_numpy(g['tags']).to(DEV)
+    lens = g['lengths'].tolist()
+    f32 = dtype == 'fp32'
+    loss = m.loss(x, lengths, tags)
+    loss.backward()
+    assert abs(loss.item() - float(g[f'{tag}.loss'])) < (2e-6 if f32 else 2e-2) * max(1.0, abs(float(g[f'{tag}.loss'])))
+    _check_grads(m, {k[len(tag) + 3:]: v for k, v in g.items() if k.startswith(tag + '.g.')}, rtol=2e-3 if f32 else 0.1,
+                 atol=2e-6 if f32 else 5e-3)
+    for th in (0.4, 0.5, None):
+        m.th = th
+        scores, got = m(x, lengths)
+        ref_tags = H.split_tags(g[f'{tag}.tags{th if th is not None else "default"}'], lens)
+        np.testing.assert_allclose(scores.cpu().numpy(), g[f'{tag}.scores'], atol=1e-5 if f32 else 5e-2, rtol=0)
+        if f32:
+            assert got == ref_tags
+        else:
+            _margin_equal(got, ref_tags, g[f'{tag}.scores'], lens, th or 0.4, 0.03, bce=loss_fn != 'CrossEntropy')
+
+
+def test_bilstm_output_covers_max_length_only():
+    from multimodaltopicsegmentation_amd import BiLSTM
+    g = H.load('g1_bilstm_small')
+    D, Hd, NL = [int(v) for v in g['cfg']]
+    m = _load_into(BiLSTM(2, D, Hd, num_layers=NL, loss_fn='FocalLoss', compute_dtype='fp32'),
+                   {k[5:]: v for k, v in g.items() if k.startswith('Fo.w.')})
+    scores, tags = m(torch.from_numpy(g['x']).to(DEV), torch.tensor([5, 3, 1, 2, 4]))
+    assert scores.shape == (5, 5, 1) and [len(t) for t in tags] == [5, 3, 1, 2, 4]
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_late_fusion_small(dtype):
+    from multimodaltopicsegmentation_amd import TextSegmenter
+    g = H.load('g7_latefusion_small')
+    D1, D2, Hd, NL = [int(v) for v in g['cfg']]
+    ts = TextSegmenter(2, [D1, D2], Hd, num_layers=NL, architecture='BiLSTMLateFusion', loss_fn='FocalLoss', compute_dtype=dtype)
+    assert ts.double_input
+    m = _load_into(ts.model, {k[2:]: v for k, v in g.items() if k.startswith('w.')})
+    f32 = dtype == 'fp32'
+    batch = {'src_tokens': torch.from_numpy(g['x1']).to(DEV), 'src_tokens2': torch.from_numpy(g['x2']).to(DEV),
+             'src_lengths': torch.from_numpy(g['lengths']), 'tgt_tokens': torch.from_numpy(g['tags']).to(DEV)}
+    loss = ts.training_step(batch, 0)
+    loss.backward()
+    assert abs(loss.item() - float(g['loss'])) < (2e-6 if f32 else 2e-2)
+    _check_grads(m, {k[2:]: v for k, v in g.items() if k.startswith('g.')}, rtol=2e-3 if f32 else 0.1, atol=2e-6 if f32 else 5e-3)
+    m.th = 0.5
+    scores, got = m(batch['src_tokens'], batch['src_tokens2'], batch['src_lengths'])
+    np.testing.assert_allclose(scores.cpu().numpy(), g['scores'], atol=1e-5 if f32 else 5e-2, rtol=0)
+    if f32:
+        assert got == H.split_tags(g['tags0.5'], g['lengths'].tolist())
+
+
+def test_bilstm_1792_fp32():
+    from multimodaltopicsegmentation_amd import BiLSTM
+    g = H.load('g2_bilstm_1792')
+    D, Hd, NL = [int(v) for v in g['cfg']]
+    shapes = H.bilstm_param_shapes(D, Hd, NL, 1)
+    shapes['classification.weight'] = (1, 2 * Hd)
+    shapes['classification.bias'] = (1,)
+    m = _load_into(BiLSTM(2, D, Hd, num_layers=NL, loss_fn='FocalLoss', compute_dtype='fp32'),
+                   {k: H.seeded_param(k, s, int(g['seed'])) for k, s in shapes.items()})
+    x = torch.from_numpy(g['x'].astype(np.float32)).to(DEV)
+    lengths, tags = torch.from_numpy(g['lengths']), torch.from_numpy(g['tags']).to(DEV)
+    loss = m.loss(x, lengths, tags)
+    loss.backward()
+    assert abs(loss.item() - float(g['loss'])) < 5e-6
+    m.th = 0.5
+    scores, got = m(x, lengths)
+    np.testing.assert_allclose(scores.cpu().numpy(), g['scores'], atol=5e-5, rtol=0)
+    assert got == H.split_tags(g['tags0.5'], g['lengths'].tolist())
+    for n, p in m.named_parameters():
+        got_g = p.grad.detach().cpu().numpy()
+        np.testing.assert_allclose(H.checksum(got_g)[1:], g['gsum.' + n][1:], rtol=2e-3, atol=1e-9, err_msg=n)
+
+
+# ------------------------------------------------------------------------------------------------ CRF (a12)
+def test_birnn_crf_composition():
+    from multimodaltopicsegmentation_amd import TextSegmenter
+    g = H.load('g5_crf')
+    D, Hd, NL = [int(v) for v in g['c.cfg']]
+    ts = TextSegmenter(2, D, Hd, num_layers=NL, architecture='biLSTMCRF', compute_dtype='fp32')
+    m = _load_into(ts.model, {k[4:]: v for k, v in g.items() if k.startswith('c.w.')})
+    x, lengths = torch.from_numpy(g['c.x']).to(DEV), torch.from_numpy(g['lengths'])
+    loss = m.loss(x, lengths, torch.from_numpy(g['tags']).to(DEV))
+    loss.backward()
+    assert abs(loss.item() - float(g['c.loss'])) < 2e-5
+    _check_grads(m, {k[4:]: v for k, v in g.items() if k.startswith('c.g.')}, rtol=3e-3, atol=3e-6)
+    score, paths = m(x, lengths)
+    np.testing.assert_allclose(score.cpu().numpy(), g['c.viterbi_score'], rtol=1e-5)
+    assert [v for p in paths for v in p] == g['c.viterbi_paths'].tolist()
+
+
+# ------------------------------------------------------------------------------------------------ boundary: steps, optimizers, errors
+def test_text_segmenter_steps_and_errors():
+    from multimodaltopicsegmentation_amd import TextSegmenter
+    with pytest.raises(ValueError, match='No other architectures implemented yet'):
+        TextSegmenter(2, 16, 8, architecture='nope')
+    with pytest.raises(ValueError, match='Choose one of CrossEntropy'):
+        TextSegmenter(2, 16, 8, architecture='BiLSTM', loss_fn='nope')
+    with pytest.raises(AssertionError):
+        TextSegmenter(2, 16, 8, architecture='Transformer', attention_window=15, nheads=4)     # odd window rejected
+    ts = TextSegmenter(2, 64, 32, num_layers=1, architecture='Transformer', loss_fn='FocalLoss', nheads=4, attention_window=8,
+                       threshold=0.5, optimizer='Adam', lr=1e-3).to(DEV)
+    opt = ts.configure_optimizers()
+    assert set(opt) == {'optimizer', 'lr_scheduler'} and opt['lr_scheduler']['monitor'] == 'val_loss'
+    assert opt['optimizer'].defaults['eps'] == 1e-7
+    g = torch.Generator().manual_seed(0)
+    batch = {'src_tokens': torch.randn(4, 30, 64, generator=g).to(DEV), 'src_lengths': torch.tensor([30, 12, 30, 7]),
+             'tgt_tokens': (torch.rand(4, 30, generator=g) < 0.2).float().to(DEV), 'src_tokens2': None, 'id': torch.arange(4), 'domain': None}
+    x_before = batch['src_tokens'].clone()
+    losses = []
+    for it in range(8):
+        opt['optimizer'].zero_grad()
+        loss = ts.training_step(batch, it)
+        loss.backward()
+        opt['optimizer'].step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0]                      # torch Adam on the flat-view parameters trains the HIP model
+    assert torch.equal(batch['src_tokens'], x_before)  # the model must not mutate src_tokens
+    vl = ts.validation_step(batch, 0)
+    assert vl.item() > 0
+    res = ts.test_step(batch, 0)
+    assert {'test_loss', 'F1_loss', 'WD_loss', 'threshold'} <= set(res)
+    tags = ts.predict_step(batch, 0)
+    assert [len(t) for t in tags] == [30, 12, 30, 7]
+    ts2 = TextSegmenter(2, 64, 32, architecture='BiLSTM', search_threshold=True).to(DEV)
+    with pytest.raises(NotImplementedError):
+        ts2.test_step(batch, 0)
+
+
+def test_state_dict_roundtrip_and_dead_keys():
+    from multimodaltopicsegmentation_amd import TextSegmenter
+    a = TextSegmenter(2, 64, 32, num_layers=1, architecture='Transformer', loss_fn='FocalLoss', nheads=4, attention_window=8).to(DEV)
+    sd = {k: v.clone() for k, v in a.state_dict().items()}
+    # a reference checkpoint also carries HF's dead tensors: they must be ignored
+    sd['model.model.model.embeddings.word_embeddings.weight'] = torch.zeros(10, 64)
+    sd['model.model.model.pooler.dense.weight'] = torch.zeros(64, 64)
+    sd['model.model.model.encoder.layer.0.attention.self.query_global.weight'] = torch.zeros(64, 64)
+    b = TextSegmenter(2, 64, 32, num_layers=1, architecture='Transformer', loss_fn='FocalLoss', nheads=4, attention_window=8)
+    b.load_state_dict(sd)
+    b = b.to(DEV)
+    x = torch.randn(2, 20, 64, device=DEV)
+    lens = torch.tensor([20, 11])
+    s1, _ = a.model(x, lens)
+    s2, _ = b.model(x, lens)
+    assert torch.equal(s1, s2)
