@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Benchmark of the tagger hot path on MI355X (contract: see the task brief / DESIGN.md §Measurement).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = forward + backward + Adam(eps 1e-7) of the restricted-window transformer tagger (BASELINE.json
+configs[1]: d=1792 early-fused embeddings, 8 heads, ff=256, one-sided window 15, 1 layer, focal loss, bf16) on one
+synthetic batch of 64 documents x 256 sentences per GPU, inputs resident in HBM.  Weak scaling: every rank gets its
+own 64 documents; gradients are all-reduced over RCCL.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def fwd_bwd_mflop_per_sentence(D, ff, radius, n_layers, n_out=1):
+    """MAC = 2 FLOP, fwd+bwd = 3 x fwd."""
+    macs = 0
+    for li in range(n_layers):
+        r = radius * (n_layers - li)
+        macs += 3 * D * D + D * D + 2 * (2 * r + 1) * D + 2 * D * ff
+    macs += n_out * D
+    return macs * 2 * 3 / 1e6
+
+
+def synthetic_batch(B, L, D, rank, device, D2=None):
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.randn(B, L, D, generator=g)
+    y = (torch.rand(B, L, generator=g) < 0.05).float()
+    y[:, -1] = 0.0                                             # utils/load_datasets_precomputed.py:172
+    batch = {'src_tokens': x.to(device), 'src_lengths': torch.full((B,), L, dtype=torch.int64), 'tgt_tokens': y.to(device),
+             'src_tokens2': None, 'id': torch.arange(B), 'domain': None}
+    if D2:
+        batch['src_tokens2'] = torch.randn(B, L, D2, generator=g).to(device)
+    return batch
+
+
+def cpu_baseline(args, D, ff, heads, window, n_layers):
+    """The CPU oracle (a port of the reference's arithmetic, oracle/restatement.py) timed on this box's host cores on a
+    bounded sample of the same workload: fwd + bwd + Adam, fp32."""
+    from oracle import restatement as R
+    from tests import helpers as H
+    Bc = args.cpu_docs
+    cores = torch.get_num_threads()
+    p = H.seeded_params(H.band_param_shapes(D, ff, n_layers, 1, max_pos=args.seq + 2), 7, torch.float32, True)
+    opt = torch.optim.Adam(list(p.values()), lr=1e-3, eps=1e-7)
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(Bc, args.seq, D, generator=g)
+    y = (torch.rand(Bc, args.seq, generator=g) < 0.05).float()
+    lengths = torch.full((Bc,), args.seq)
+    radii = R.pyramidal_radii(n_layers, window)
+    times = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = R.tagger_loss(R.transformer_scores(x, lengths, p, heads, radii), lengths, y, 'FocalLoss')
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    best = min(times[1:])
+    return {'value': Bc * args.seq / best, 'unit': 'sentences/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{Bc} docs x {args.seq} sentences x {D}-d, same model, fp32 fwd+bwd+Adam, best of 2 after 1 warm-up '
+                      f'({best:.2f} s/step)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--docs', type=int, default=64, help='documents per GPU')
+    ap.add_argument('--seq', type=int, default=256, help='sentences per document')
+    ap.add_argument('--dim', type=int, default=1792)
+    ap.add_argument('--arch', default='transformer', choices=['transformer', 'bilstm', 'bilstm_crf', 'latefusion'])
+    ap.add_argument('--layers', type=int, default=None)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--cpu-docs', type=int, default=8)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timer', action='store_true')
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=device)          # backend "nccl" is RCCL on ROCm
+
+    from multimodaltopicsegmentation_amd import ops
+    from multimodaltopicsegmentation_amd.rnn_taggers import BiLSTM, BiLSTMLateFusion, BiRnnCrf
+    from multimodaltopicsegmentation_amd.taggers import Transformer_segmenter
+    from multimodaltopicsegmentation_amd.trainer import NativeTrainer
+
+    torch.manual_seed(1234)
+    D, heads, ff, window = args.dim, 8, 256, 30                    # window 30 = one-sided radius 15 ("win=15")
+    D2 = None
+    if args.arch == 'transformer':
+        n_layers = args.layers or 1
+        model = Transformer_segmenter(2, D, ff, num_layers=n_layers, nheads=heads, loss_fn='FocalLoss', window_size=window,
+                                      compute_dtype=args.dtype, seed=1234)
+        mflop = fwd_bwd_mflop_per_sentence(D, ff, window // 2, n_layers)
+        wl = f'restricted-window transformer tagger d={D} heads={heads} ff={ff} radius={window // 2} layers={n_layers} focal loss'
+    elif args.arch == 'bilstm':
+        n_layers = args.layers or 2
+        model = BiLSTM(2, D, 256, num_layers=n_layers, loss_fn='FocalLoss', compute_dtype=args.dtype, seed=1234)
+        mflop = 34.61 if (D == 1792 and n_layers == 2) else None
+        wl = f'BiLSTM tagger d={D} H=256 layers={n_layers} focal loss'
+    elif args.arch == 'bilstm_crf':
+        n_layers = args.layers or 2
+        model = BiRnnCrf(2, D, 256, num_layers=n_layers, compute_dtype=args.dtype, seed=1234)
+        mflop = 34.62 if (D == 1792 and n_layers == 2) else None
+        wl = f'BiLSTM + CRF head d={D} H=256 layers={n_layers} CRF NLL'
+    else:
+        n_layers = args.layers or 2
+        D, D2 = 1024, 768
+        model = BiLSTMLateFusion(2, [D, D2], 256, num_layers=n_layers, loss_fn='FocalLoss', compute_dtype=args.dtype, seed=1234)
+        mflop = 47.19 if n_layers == 2 else None
+        wl = f'late fusion (concat) two BiLSTMs {D}+{D2} H=256 layers={n_layers} focal loss'
+    model = model.to(device)
+    trainer = NativeTrainer(model, lr=1e-3, optimizer='Adam')
+    batch = synthetic_batch(args.docs, args.seq, D, rank, device, D2)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(batch)
+    sync()
+    # per-launch HIP events (torch.cuda.Event on the launch stream) around the GEMM / band-attention launches of the
+    # timed region itself; recording is asynchronous and costs ~1 us of host time per event
+    timer = None if args.no_kernel_timer else ops.KernelTimer()
+    ops.TIMER = timer
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(batch)
+    sync()
+    elapsed = time.perf_counter() - t0
+    ops.TIMER = None
+    loss_val = float(loss)
+    ksum = timer.summary() if timer is not None else {}
+    if world > 1:
+        t = torch.tensor([elapsed], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    if rank == 0:
+        sentences = world * args.docs * args.seq * args.steps
+        value = sentences / elapsed
+        out = {
+            'metric': 'sentences/sec (fwd+bwd)', 'value': value, 'unit': 'sentences/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': f'BASELINE configs[1]: {wl}, {args.docs} docs x {args.seq} sentences per GPU, '
+                                   f'fwd+bwd+Adam(eps 1e-7), inputs resident in HBM',
+                       'global_batch_docs': world * args.docs, 'sentences_per_doc': args.seq, 'parallelism': f'dp{world} (document-sharded, RCCL all-reduce)'},
+            'final_loss': loss_val,
+        }
+        if mflop:
+            out['model_tflops'] = value * mflop / 1e6
+            out['model_mfma_frac'] = out['model_tflops'] / (MFMA_BF16_PEAK_TFLOPS * world)
+        # roofline of the dominant kernel (by total time): one GEMM symbol = one (layout, output dtype) instantiation
+        names = {0: 'gemm_bf16_kernel<NT,bf16> (forward projections)', 1: 'gemm_bf16_kernel<NN,bf16> (data gradients)',
+                 2: 'gemm_bf16_kernel<TN,f32> (weight gradients)'}
+        per_sym = {}
+        other = {}
+        for tag, (n, ms) in ksum.items():
+            if tag[0] == 'gemm':
+                _, layout, a_dt, c_dt, M, N, K = tag
+                d = per_sym.setdefault((layout, c_dt), {'launches': 0, 'ms': 0.0, 'flop': 0.0})
+                d['launches'] += n
+                d['ms'] += ms
+                d['flop'] += n * 2.0 * M * N * K
+            else:
+                other[tag[0]] = {'launches': n, 'avg_us': 1e3 * ms / n}
+        if per_sym:
+            (layout, c_dt), dom = max(per_sym.items(), key=lambda kv: kv[1]['ms'])
+            ach = dom['flop'] / (dom['ms'] * 1e-3) / 1e12
+            out['roofline'] = {'bound': 'mfma', 'kernel': names.get(layout, str(layout)), 'achieved': ach, 'peak': MFMA_BF16_PEAK_TFLOPS,
+                               'unit': 'TFLOP/s', 'frac': ach / MFMA_BF16_PEAK_TFLOPS, 'traffic': None,
+                               'launches_timed': dom['launches'], 'avg_launch_us': 1e3 * dom['ms'] / dom['launches'],
+                               'algorithmic_gflop_per_launch': dom['flop'] / dom['launches'] / 1e9}
+            out['kernels'] = {names.get(l, str(l)): {'launches': d['launches'], 'avg_us': 1e3 * d['ms'] / d['launches'],
+                                                     'tflops': d['flop'] / (d['ms'] * 1e-3) / 1e12} for (l, c), d in per_sym.items()}
+            # the HBM-bound headline kernel: band attention, 14 336 algorithmic bytes per sentence (bf16 q,k,v in, ctx out)
+            if 'band_fwd' in other:
+                by = args.docs * args.seq * 4 * D * (2 if args.dtype == 'bf16' else 4)
+                gbs = by / (other['band_fwd']['avg_us'] * 1e-6) / 1e9
+                out['kernels']['band_attn_fwd'] = {**other['band_fwd'], 'algorithmic_GBps': gbs, 'hbm_frac': gbs / HBM_PEAK_GBS}
+            if 'band_bwd' in other:
+                out['kernels']['band_attn_bwd (2 launches)'] = other['band_bwd']
+        if world == 1 and not args.no_cpu_baseline and args.arch == 'transformer':
+            out['cpu_baseline'] = cpu_baseline(args, D, ff, heads, window, n_layers)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -10,6 +10,38 @@ from ._lib import check, lib, ptr, stream_ptr, dtype_code
 
 _ws_cache = {}
 
+TIMER = None   # set to a KernelTimer() to time individual launches with HIP events on the launch stream (bench.py)
+
+
+class KernelTimer:
+    """Per-launch HIP-event timing (torch.cuda.Event on torch's current stream = the stream the kernels run on)."""
+
+    def __init__(self):
+        self.records = {}          # tag -> list of (start_event, end_event)
+
+    def begin(self, tag):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.records.setdefault(tag, []).append((s, e))
+        s.record()
+        return e
+
+    def summary(self):
+        """tag -> (launches, total_ms); call after torch.cuda.synchronize()."""
+        return {t: (len(v), sum(s.elapsed_time(e) for s, e in v)) for t, v in self.records.items()}
+
+
+class _timed:
+    def __init__(self, tag):
+        self.tag = tag
+
+    def __enter__(self):
+        self.e = TIMER.begin(self.tag) if TIMER is not None else None
+
+    def __exit__(self, *a):
+        if self.e is not None:
+            self.e.record()
+        return False
+
 
 def _scratch(nbytes, device, tag):
     """Grow-only scratch buffers keyed by (device, tag): never reallocated inside a steady-state step."""
@@ -41,9 +73,10 @@ def gemm(layout, A, B, out, *, M, N, K, lda=None, ldb=None, ldc=None, bias=None,
     lda = lda if lda is not None else A.stride(0)
     ldb = ldb if ldb is not None else B.stride(0)
     ldc = ldc if ldc is not None else out.stride(0)
-    check(lib.mts_gemm(stream_ptr(), a_dt, c_dt, layout, M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc, ptr(bias),
-                       ptr(residual), residual.stride(0) if residual is not None else 0, ptr(aux),
-                       aux.stride(0) if aux is not None else 0, epi, float(colscale or 1.0), int(ncols_scaled)))
+    with _timed(('gemm', layout, a_dt, c_dt, M, N, K)):
+        check(lib.mts_gemm(stream_ptr(), a_dt, c_dt, layout, M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc, ptr(bias),
+                           ptr(residual), residual.stride(0) if residual is not None else 0, ptr(aux),
+                           aux.stride(0) if aux is not None else 0, epi, float(colscale or 1.0), int(ncols_scaled)))
     return out
 
 
@@ -110,13 +143,15 @@ def band_slots(radius):
 
 
 def band_attn_fwd(qkv, lengths, B, Lq, D, heads, radius, ctx, probs):
-    check(lib.mts_band_attn_fwd(stream_ptr(), dtype_code(qkv.dtype), B, Lq, D, heads, radius, ptr(qkv), ptr(lengths), ptr(ctx), ptr(probs)))
+    with _timed(('band_fwd', B, Lq, D, heads, radius)):
+        check(lib.mts_band_attn_fwd(stream_ptr(), dtype_code(qkv.dtype), B, Lq, D, heads, radius, ptr(qkv), ptr(lengths), ptr(ctx), ptr(probs)))
 
 
 def band_attn_bwd(qkv, lengths, probs, dctx, B, Lq, D, heads, radius, dqkv, dscores):
     q_scale = 1.0 / math.sqrt(D // heads)
-    check(lib.mts_band_attn_bwd(stream_ptr(), dtype_code(qkv.dtype), B, Lq, D, heads, radius, q_scale, ptr(qkv), ptr(lengths),
-                                ptr(probs), ptr(dctx), ptr(dqkv), ptr(dscores)))
+    with _timed(('band_bwd', B, Lq, D, heads, radius)):
+        check(lib.mts_band_attn_bwd(stream_ptr(), dtype_code(qkv.dtype), B, Lq, D, heads, radius, q_scale, ptr(qkv), ptr(lengths),
+                                    ptr(probs), ptr(dctx), ptr(dqkv), ptr(dscores)))
 
 
 def tagger_loss(kind, scores, targets, lengths, alpha, gamma, loss_out, dscores):
