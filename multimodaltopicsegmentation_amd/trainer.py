@@ -34,7 +34,8 @@ def shard_batch(batch, rank, world):
 class NativeTrainer:
     def __init__(self, model, lr=1e-3, optimizer='Adam', process_group=None, token_weighted=False):
         """model: a tagger from taggers.py / rnn_taggers.py (or a TextSegmenter, whose .model is used)."""
-        self.model = getattr(model, 'model', model)
+        # a TextSegmenter wraps the tagger in .model; a bare tagger may itself own a parameter container called "model"
+        self.model = model.model if hasattr(model, 'training_step') else model
         self.lr, self.kind = float(lr), optimizer
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
