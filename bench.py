@@ -157,6 +157,12 @@ def main():
     ops.TIMER = None
     loss_val = float(loss)
     ksum = timer.summary() if timer is not None else {}
+    if rank == 0 and os.environ.get('MTS_BENCH_DETAIL'):
+        for tag, (n, ms) in sorted(ksum.items(), key=lambda kv: -kv[1][1]):
+            extra = ''
+            if tag[0] == 'gemm':
+                extra = f' {2.0 * tag[4] * tag[5] * tag[6] * n / (ms * 1e-3) / 1e12:7.1f} TFLOP/s'
+            print(f'[detail] {str(tag):60s} n={n:4d} avg={1e3 * ms / n:9.1f} us{extra}', file=sys.stderr)
     if world > 1:
         t = torch.tensor([elapsed], device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -52,7 +52,7 @@ typedef enum { MTS_NT = 0, MTS_NN = 1, MTS_TN = 2 } mts_gemm_layout;
 #define MTS_EPI_RESIDUAL  2u   /* += residual[m,n]  (act dtype, ld = ldr)                 */
 #define MTS_EPI_GELU      4u   /* C = gelu_erf(acc); pre-activation stored to `aux` if non-null */
 #define MTS_EPI_COLSCALE  8u   /* columns n < ncols_scaled are multiplied by colscale (q / sqrt(hd)) */
-#define MTS_EPI_ACCUM    16u   /* C += result (fp32 C only; used for split-K weight gradients) */
+#define MTS_EPI_ACCUM    16u   /* C += result (fp32 C only) */
 
 const char* mts_last_error(void);
 /* version / build info: "mts-hip <n> gfx950" */
@@ -64,11 +64,14 @@ const char* mts_version(void);
  * the LSTM input projection inside aten::lstm (models/NeuralArchitectures.py:113) and the tagger
  * heads (models/CRF.py:299-310, :554-566); plus their autograd backward.
  * a_dtype: dtype of A and B (and residual/aux); c_dtype: dtype of C (MTS_F32 or a_dtype).
+ * workspace (optional, workspace_bytes): scratch for split-K partial tiles of weight-gradient shapes (fp32 C,
+ * no epilogue besides MTS_EPI_ACCUM); without it such shapes run unsplit.  Partials are summed in a fixed
+ * order, so results are bitwise reproducible.
  * ------------------------------------------------------------------------------------------- */
 int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int M, int N, int K,
              const void* A, int lda, const void* B, int ldb, void* C, int ldc,
              const float* bias, const void* residual, int ldr, void* aux, int ldaux,
-             unsigned epilogue, float colscale, int ncols_scaled);
+             unsigned epilogue, float colscale, int ncols_scaled, void* workspace, size_t workspace_bytes);
 
 /* column sums of an [M,N] activation matrix into fp32 out[N] (bias gradients); deterministic two-stage
  * reduction through `partial` (mts_colsum_workspace(N) bytes). */

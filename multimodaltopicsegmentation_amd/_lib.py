@@ -30,7 +30,7 @@ _vp, _i, _f, _u, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint, C.c_size_t
 SIGNATURES = {
     'mts_last_error': (C.c_char_p, []),
     'mts_version': (C.c_char_p, []),
-    'mts_gemm': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _u, _f, _i]),
+    'mts_gemm': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _u, _f, _i, _vp, _sz]),
     'mts_colsum_workspace': (_sz, [_i]),
     'mts_colsum': (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     'mts_cast': (_i, [_vp, _i, _vp, _vp, _sz]),

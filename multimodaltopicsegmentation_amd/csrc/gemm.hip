@@ -16,6 +16,7 @@
 // vectors in the epilogue.
 #include <algorithm>
 #include <math.h>
+#include <stdlib.h>
 #include "common.h"
 
 struct GemmArgs {
@@ -26,7 +27,7 @@ struct GemmArgs {
   unsigned epi;
   float colscale; int ncols_scaled;
   int ksplit;      // K elements per blockIdx.z slice (multiple of 64)
-  int atomic_out;  // 1: fp32 atomicAdd into C (split-K)
+  float* slab;     // split-K: slice z stores its fp32 partial tile to slab[z][M][N] (plain stores); reduced afterwards
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -60,9 +61,8 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, int m, int n, float
     TC* c = reinterpret_cast<TC*>(a.C) + (size_t)m * a.ldc + n;
     if constexpr (sizeof(TC) == 4) {
       float* cf = reinterpret_cast<float*>(c);
-      if (a.atomic_out) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) atomicAdd(cf + i, v[i]);
+      if (a.slab) {
+        store4<float>(a.slab + ((size_t)blockIdx.z * a.M + m) * a.N + n, v);
       } else if (epi & MTS_EPI_ACCUM) {
         float o[4];
         load4<float>(cf, o);
@@ -88,7 +88,7 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, int m, int n, float
       TC* c = reinterpret_cast<TC*>(a.C) + (size_t)m * a.ldc + n + i;
       if constexpr (sizeof(TC) == 4) {
         float* cf = reinterpret_cast<float*>(c);
-        if (a.atomic_out) atomicAdd(cf, x);
+        if (a.slab) a.slab[((size_t)blockIdx.z * a.M + m) * a.N + n + i] = x;
         else if (epi & MTS_EPI_ACCUM) *cf += x;
         else *cf = x;
       } else {
@@ -131,7 +131,15 @@ __device__ __forceinline__ bf16x8 frag_strided(const char* tile, int kbase, int 
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int LAYOUT, typename TC>
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+// GLDS = true: both operands go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write
+// instructions -- the ds_write_b128 pass of the register-staged form costs about as many LDS cycles as all the
+// fragment reads of a K-step).  A wave-instruction writes 1 KiB lane-linear, so the XOR swizzles of the two LDS
+// images are applied to the per-lane SOURCE address (same involution as on the read side).  Needs K % 64 == 0;
+// rows/columns past M/N are clamped to valid memory (they only feed outputs that are never stored).
+template <int LAYOUT, typename TC, bool GLDS>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
   constexpr bool A_KMAJOR = (LAYOUT != MTS_TN);
   constexpr bool B_KMAJOR = (LAYOUT == MTS_NT);
@@ -215,15 +223,56 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto dma_tile = [&](int kt, int buf) {
+    const int k0 = kbeg + kt * BK;
+    char* sa = smem + buf * (2 * TILE_BYTES);
+    char* sb = sa + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int piece = wave_u * 4 + i;            // 1 KiB piece of the 16 KiB image, wave-uniform
+      const bf16_t* srca;
+      if constexpr (A_KMAJOR) {
+        const int row = piece * 8 + (lane >> 3), pos = lane & 7;
+        const int ch = pos ^ ((row >> 1) & 7);
+        srca = A + (size_t)min(bm0 + row, a.M - 1) * a.lda + k0 + ch * 8;
+      } else {
+        const int kr = piece * 4 + (lane >> 4), c16 = lane & 15;
+        const int ch = ((((c16 >> 1) ^ strided_key(kr))) << 1) | (c16 & 1);
+        srca = A + (size_t)(k0 + kr) * a.lda + min(bm0 + ch * 8, a.M - 8);
+      }
+      __builtin_amdgcn_global_load_lds((gptr_t*)srca, (lptr_t*)(sa + piece * 1024), 16, 0, 0);
+      const bf16_t* srcb;
+      if constexpr (B_KMAJOR) {
+        const int row = piece * 8 + (lane >> 3), pos = lane & 7;
+        const int ch = pos ^ ((row >> 1) & 7);
+        srcb = B + (size_t)min(bn0 + row, a.N - 1) * a.ldb + k0 + ch * 8;
+      } else {
+        const int kr = piece * 4 + (lane >> 4), c16 = lane & 15;
+        const int ch = ((((c16 >> 1) ^ strided_key(kr))) << 1) | (c16 & 1);
+        srcb = B + (size_t)(k0 + kr) * a.ldb + min(bn0 + ch * 8, a.N - 8);
+      }
+      __builtin_amdgcn_global_load_lds((gptr_t*)srcb, (lptr_t*)(sb + piece * 1024), 16, 0, 0);
+    }
+  };
+
   if (nk > 0) {
-    load_tile(0);
-    store_tile(0);
+    if constexpr (GLDS) {
+      dma_tile(0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      load_tile(0);
+      store_tile(0);
+    }
   }
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);  // global loads stay in flight behind the MFMAs below
+    if (kt + 1 < nk) {
+      if constexpr (GLDS) dma_tile(kt + 1, buf ^ 1);   // lands in the other buffer while this one feeds the MFMAs
+      else load_tile(kt + 1);                          // global loads stay in flight behind the MFMAs below
+    }
     const char* sa = smem + buf * (2 * TILE_BYTES);
     const char* sb = sa + TILE_BYTES;
 #pragma unroll
@@ -242,7 +291,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // C^T tile
     }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
+    if constexpr (GLDS) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
+    } else {
+      if (kt + 1 < nk) store_tile(buf ^ 1);
+    }
     __syncthreads();
   }
 
@@ -343,6 +396,25 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
   out[n] = accumulate ? out[n] + s : s;
 }
 
+// C[m,n] (+)= sum_z slab[z][m][n]  -- fixed summation order, so split-K weight gradients are bitwise reproducible
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int splits, int M, int N, float* __restrict__ C,
+                                                            int ldc, int accumulate) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = N / 4;
+  if (idx >= (size_t)M * n4) return;
+  const int m = (int)(idx / n4), n = 4 * (int)(idx % n4);
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (accumulate) load4<float>(C + (size_t)m * ldc + n, s);
+  const size_t plane = (size_t)M * N;
+  for (int z = 0; z < splits; ++z) {
+    float v[4];
+    load4<float>(slab + z * plane + (size_t)m * N + n, v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[i] += v[i];
+  }
+  store4<float>(C + (size_t)m * ldc + n, s);
+}
+
 template <typename T> __global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, size_t n) {
   size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
@@ -398,15 +470,23 @@ extern "C" int mts_cast(void* stream, int dst_dtype, const float* src, void* dst
   return MTS_OK;
 }
 
+static int g_gemm_glds = -1;   // MTS_GEMM_GLDS=0 forces the register-staged form (A/B testing)
+
 template <int LAYOUT, typename TC>
 static void launch_bf16(const GemmArgs& a, int splits, hipStream_t st) {
   const int nt = ceil_div(a.M, BM) * ceil_div(a.N, BN);
-  hipLaunchKernelGGL((gemm_bf16_kernel<LAYOUT, TC>), dim3(nt, 1, splits), dim3(256), 4 * TILE_BYTES, st, a);
+  if (g_gemm_glds < 0) {
+    const char* e = getenv("MTS_GEMM_GLDS");
+    g_gemm_glds = (e && e[0] == '0') ? 0 : 1;
+  }
+  const bool glds = g_gemm_glds && (a.K % BK == 0) && (a.ksplit % BK == 0) && a.M >= 8 && a.N >= 8;
+  if (glds) hipLaunchKernelGGL((gemm_bf16_kernel<LAYOUT, TC, true>), dim3(nt, 1, splits), dim3(256), 4 * TILE_BYTES, st, a);
+  else hipLaunchKernelGGL((gemm_bf16_kernel<LAYOUT, TC, false>), dim3(nt, 1, splits), dim3(256), 4 * TILE_BYTES, st, a);
 }
 
 extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int M, int N, int K, const void* A, int lda,
                         const void* B, int ldb, void* C, int ldc, const float* bias, const void* residual, int ldr,
-                        void* aux, int ldaux, unsigned epilogue, float colscale, int ncols_scaled) {
+                        void* aux, int ldaux, unsigned epilogue, float colscale, int ncols_scaled, void* workspace, size_t workspace_bytes) {
   MTS_CHECK_ARG(M > 0 && N > 0 && K > 0, "mts_gemm: bad shape M=%d N=%d K=%d", M, N, K);
   MTS_CHECK_ARG(A && B && C, "mts_gemm: null operand");
   MTS_CHECK_ARG(layout == MTS_NT || layout == MTS_NN || layout == MTS_TN, "mts_gemm: bad layout %d", layout);
@@ -420,7 +500,7 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.residual = residual; a.aux = aux;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.ldaux = ldaux;
   a.epi = epilogue; a.colscale = colscale; a.ncols_scaled = ncols_scaled;
-  a.ksplit = K; a.atomic_out = 0;
+  a.ksplit = K; a.slab = nullptr;
 
   if (a_dtype == MTS_F32) {
     StrideArgs s;
@@ -444,24 +524,29 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
   MTS_UNSUPPORTED(!(epilogue & MTS_EPI_RESIDUAL) || (ldr % 4 == 0 && ((uintptr_t)residual % 8) == 0), "mts_gemm(bf16): residual alignment");
   MTS_UNSUPPORTED(!aux || (ldaux % 4 == 0 && ((uintptr_t)aux % 8) == 0), "mts_gemm(bf16): aux alignment");
 
+  // Split-K for weight-gradient shapes (few output tiles, K = all tokens): pick the split that minimises
+  // rounds-of-workgroups x K/split + the slab round trip; partial tiles go to `workspace` with plain stores and a
+  // second kernel sums them in a fixed order (no float atomics: deterministic, and 4-5x the atomic byte rate).
   int splits = 1;
-  if (c_dtype == MTS_F32 && !(epilogue & MTS_EPI_GELU)) {
-    // weight-gradient shapes: few output tiles, very long K -> split K over blockIdx.z (fp32 atomics)
+  const unsigned plain = epilogue & ~MTS_EPI_ACCUM;
+  if (c_dtype == MTS_F32 && plain == 0 && workspace && N % 4 == 0 && K >= 2048) {
     const int nt = ceil_div(M, BM) * ceil_div(N, BN);
-    const int want = ceil_div(2048, nt);
-    const int maxs = K / 1024;
-    splits = want < 1 ? 1 : want;
-    if (splits > maxs) splits = maxs;
-    if (splits < 1) splits = 1;
+    const double slots = 512.0, t_k = 0.021, bw = 3500.0;   // us per K element per round; slab MB per us ~ 3.5 TB/s
+    double best = 1e30;
+    for (int sp = 1; sp <= 32; ++sp) {
+      const int ks = ceil_div(ceil_div(K, sp), BK) * BK;
+      const int real = ceil_div(K, ks);
+      if (real != sp) continue;
+      if (sp > 1 && (size_t)sp * M * N * sizeof(float) > workspace_bytes) break;
+      const double rounds = ceil((double)nt * sp / slots);
+      const double cost = rounds * ks * t_k + (sp > 1 ? (2.0 * sp + 1.0) * M * N * 4.0 / 1e6 / bw : 0.0);
+      if (cost < best) { best = cost; splits = sp; }
+    }
   }
+  a.slab = nullptr;
   if (splits > 1) {
     a.ksplit = ceil_div(ceil_div(K, splits), BK) * BK;
-    splits = ceil_div(K, a.ksplit);
-    a.atomic_out = 1;
-    if (!(epilogue & MTS_EPI_ACCUM)) {
-      hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, st);
-      if (e != hipSuccess) { mts_set_error("mts_gemm: memset failed: %s", hipGetErrorString(e)); return MTS_ERR_LAUNCH; }
-    }
+    a.slab = (float*)workspace;
   }
   if (c_dtype == MTS_F32) {
     if (layout == MTS_NT) launch_bf16<MTS_NT, float>(a, splits, st);
@@ -472,6 +557,9 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
     else if (layout == MTS_NN) launch_bf16<MTS_NN, bf16_t>(a, splits, st);
     else launch_bf16<MTS_TN, bf16_t>(a, splits, st);
   }
+  if (splits > 1)
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((size_t)M * (N / 4) + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
+                       splits, M, N, (float*)C, ldc, (epilogue & MTS_EPI_ACCUM) ? 1 : 0);
   MTS_LAUNCH_CHECK("mts_gemm(bf16)");
   return MTS_OK;
 }

@@ -264,7 +264,8 @@ extern "C" int mts_lstm_bwd(void* stream, int dtype, int B, int L, int H, int nd
   MTS_UNSUPPORTED(mfma_ok, "mts_lstm_bwd(bf16): hidden size %d must be a multiple of 8", H);
   for (int d = 0; d < ndir; ++d) {
     int rc = mts_gemm(stream, dtype, MTS_F32, MTS_TN, 4 * H, H, B * L, (const char*)dxproj + (size_t)d * 4 * H * esz, ndir * 4 * H,
-                      hprev + (size_t)d * H * esz, ndir * H, dw_hh + (size_t)d * 4 * H * H, H, nullptr, nullptr, 0, nullptr, 0, 0u, 1.f, 0);
+                      hprev + (size_t)d * H * esz, ndir * H, dw_hh + (size_t)d * 4 * H * H, H, nullptr, nullptr, 0, nullptr, 0, 0u, 1.f, 0,
+                      nullptr, 0);
     if (rc) return rc;
   }
   return MTS_OK;

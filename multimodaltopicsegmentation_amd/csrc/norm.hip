@@ -11,7 +11,7 @@
 #include "common.h"
 
 #define ROW_WAVES 4            // waves (= rows in flight) per workgroup
-#define BWD_MAX_BLOCKS 512
+#define BWD_MAX_BLOCKS 256
 
 template <typename T, int NV> struct RowRegs {
   float v[NV][4];
@@ -346,19 +346,23 @@ __global__ __launch_bounds__(64 * ROW_WAVES) void head_bwd_params_kernel(const T
   }
 }
 
-// out[slot][e] = sum_blocks partial[block][slot][e]
+// out[slot][e] = sum_blocks partial[block][slot][e]: 64 columns x 4 block-groups per workgroup, LDS combine in a fixed order
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ partial, int nblocks, int nslots, int D,
                                                           float* out0, float* out1, float* out2, float* out3, float* out4, int len4) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float red[4][64];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + col;
   const int slot = blockIdx.y;
   float* outs[5] = {out0, out1, out2, out3, out4};
   float* o = outs[slot];
   if (!o) return;
   const int len = (slot == 4) ? len4 : D;
-  if (e >= len) return;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[((size_t)b * nslots + slot) * D + e];
-  o[e] = s;
+  if (e < len)
+    for (int b = grp; b < nblocks; b += 4) s += partial[((size_t)b * nslots + slot) * D + e];
+  red[grp][col] = s;
+  __syncthreads();
+  if (grp == 0 && e < len) o[e] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
 }
 
 // dpos[pos_offset+i,:] += sum_b dpre[b,i,:]
@@ -498,7 +502,7 @@ static int ln_bwd_launch(hipStream_t st, int rows, int D, const void* x, const v
     hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), dim3(blocks), dim3(64 * ROW_WAVES), 0, st, (const T*)x, (const T*)dy, dlogit, head_w, n_out, gamma,
                        mean, rstd, rows, D, (T*)dx, (float*)partial);
   });
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(D, 256), 3), dim3(256), 0, st, (const float*)partial, blocks, 3, D, dgamma, dbeta,
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(D, 64), 3), dim3(256), 0, st, (const float*)partial, blocks, 3, D, dgamma, dbeta,
                      dxsum, (float*)nullptr, (float*)nullptr, 0);
   MTS_LAUNCH_CHECK("layernorm_bwd");
   return MTS_OK;
@@ -575,7 +579,7 @@ extern "C" int mts_head_bwd_params(void* stream, int dtype, int rows, int D, int
   } else { mts_set_error("mts_head_bwd_params: bad dtype %d", dtype); return MTS_ERR_INVALID; }
   float* rowp[4] = {nullptr, nullptr, nullptr, nullptr};
   for (int c = 0; c < n_out; ++c) rowp[c] = dw + (size_t)c * D;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(D, 256), 5), dim3(256), 0, st, (const float*)partial, blocks, 5, D, rowp[0], rowp[1],
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(D, 64), 5), dim3(256), 0, st, (const float*)partial, blocks, 5, D, rowp[0], rowp[1],
                      rowp[2], rowp[3], db, n_out);
   MTS_LAUNCH_CHECK("mts_head_bwd_params");
   return MTS_OK;

@@ -73,10 +73,15 @@ def gemm(layout, A, B, out, *, M, N, K, lda=None, ldb=None, ldc=None, bias=None,
     lda = lda if lda is not None else A.stride(0)
     ldb = ldb if ldb is not None else B.stride(0)
     ldc = ldc if ldc is not None else out.stride(0)
+    ws, ws_bytes = None, 0
+    if layout == L.TN and c_dt == L.F32 and a_dt == L.BF16 and K >= 2048:
+        ws_bytes = min(16, max(1, K // 1024)) * M * N * 4          # room for up to 16 split-K partial planes
+        ws = _scratch(ws_bytes, A.device, 'splitk')
     with _timed(('gemm', layout, a_dt, c_dt, M, N, K)):
         check(lib.mts_gemm(stream_ptr(), a_dt, c_dt, layout, M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc, ptr(bias),
                            ptr(residual), residual.stride(0) if residual is not None else 0, ptr(aux),
-                           aux.stride(0) if aux is not None else 0, epi, float(colscale or 1.0), int(ncols_scaled)))
+                           aux.stride(0) if aux is not None else 0, epi, float(colscale or 1.0), int(ncols_scaled),
+                           ptr(ws), ws_bytes))
     return out
 
 
