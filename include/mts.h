@@ -57,6 +57,8 @@ typedef enum { MTS_NT = 0, MTS_NN = 1, MTS_TN = 2 } mts_gemm_layout;
 const char* mts_last_error(void);
 /* version / build info: "mts-hip <n> gfx950" */
 const char* mts_version(void);
+/* tuning / A-B switches: "gemm_tile" = 0 (cost model) | 128 | 256 ; "gemm_glds" = 1 (LDS-DMA staging) | 0 (register staging) */
+int mts_set_option(const char* key, int value);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense projection GEMM (MFMA for bf16, exact-fp32 VALU kernel for parity mode).
@@ -107,10 +109,9 @@ int mts_layernorm_bwd(void* stream, int dtype, int rows, int D, const void* x, c
                       const float* dlogit, const float* head_w, int n_out,
                       const float* gamma, const float* mean, const float* rstd,
                       void* dx, float* dgamma, float* dbeta, float* dxsum, void* partial);
-/* gradient of the embedding sum: dpos[pos_offset+i,:] += sum_b dpre[b,i,:]; dtype0 += sum_{b,i} dpre
- * (partial: 64*D floats of scratch) */
-int mts_embed_bwd(void* stream, int dtype, int B, int L, int D, const void* dpre, float* dpos, int pos_offset,
-                  float* dtype0, void* partial);
+/* gradient of the position table: dpos[pos_offset+i,:] += sum_b dpre[b,i,:].  (The token-type row's gradient is
+ * sum_{b,i} dpre = the `dxsum` output of the embedding LayerNorm's mts_layernorm_bwd.) */
+int mts_embed_bwd(void* stream, int dtype, int B, int L, int D, const void* dpre, float* dpos, int pos_offset);
 
 /* dy *= gelu_erf'(u) in place (FFN backward; modeling_longformer.py:1113-1116); n elements, n % 4 == 0 */
 int mts_gelu_bwd(void* stream, int dtype, size_t n, const void* u, void* dy);

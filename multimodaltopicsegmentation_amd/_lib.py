@@ -1,7 +1,7 @@
 """ctypes binding of libmts_hip.so (the C ABI declared in include/mts.h).
 
 The product path has NO fallback: if the shared library is missing or fails to load, importing this
-module raises -- build it with ``python -m multimodaltopicsegmentation_amd.build`` (hipcc, gfx950).
+module raises -- build it with ``python multimodaltopicsegmentation_amd/build.py`` (hipcc, gfx950).
 """
 import ctypes as C
 import os
@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'libmts_hip.so')
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         f'{LIB_PATH} not found: the HIP kernel library has not been built. Run '
-        '`python -m multimodaltopicsegmentation_amd.build` (needs hipcc; cross-compiles for gfx950 without a GPU). '
+        '`python multimodaltopicsegmentation_amd/build.py` (needs hipcc; cross-compiles for gfx950 without a GPU). '
         'There is no CPU/PyTorch fallback for the tagger path.')
 
 lib = C.CDLL(LIB_PATH)
@@ -30,6 +30,7 @@ _vp, _i, _f, _u, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint, C.c_size_t
 SIGNATURES = {
     'mts_last_error': (C.c_char_p, []),
     'mts_version': (C.c_char_p, []),
+    'mts_set_option': (_i, [C.c_char_p, _i]),
     'mts_gemm': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _u, _f, _i, _vp, _sz]),
     'mts_colsum_workspace': (_sz, [_i]),
     'mts_colsum': (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
@@ -38,7 +39,7 @@ SIGNATURES = {
     'mts_layernorm_fwd': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'mts_layernorm_bwd_workspace': (_sz, [_i]),
     'mts_layernorm_bwd': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    'mts_embed_bwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    'mts_embed_bwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i]),
     'mts_gelu_bwd': (_i, [_vp, _i, _sz, _vp, _vp]),
     'mts_band_slots': (_i, [_i]),
     'mts_band_attn_fwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
@@ -68,7 +69,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 if _missing:
-    raise ImportError(f'{LIB_PATH} does not export {_missing}: stale build? re-run python -m multimodaltopicsegmentation_amd.build --force')
+    raise ImportError(f'{LIB_PATH} does not export {_missing}: stale build? re-run python multimodaltopicsegmentation_amd/build.py --force')
 
 
 class MtsError(RuntimeError):

@@ -1,6 +1,6 @@
 """Build libmts_hip.so (gfx950) in-tree with hipcc.  Used by __graft_entry__.build() and by hand:
 
-    python -m multimodaltopicsegmentation_amd.build [--force]
+    python multimodaltopicsegmentation_amd/build.py [--force]
 """
 import os
 import subprocess
@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libmts_hip.so')
-SOURCES = ['gemm.hip', 'norm.hip', 'band_attn.hip', 'loss.hip', 'optim.hip', 'lstm.hip', 'crf.hip']
+SOURCES = ['gemm.hip', 'gemm256.hip', 'norm.hip', 'band_attn.hip', 'loss.hip', 'optim.hip', 'lstm.hip', 'crf.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wno-unused-result']
 
 
@@ -20,7 +20,7 @@ def _newer(a, b):
 
 def _compile(src):
     obj = os.path.join(CSRC, src.replace('.hip', '.o'))
-    deps = [os.path.join(CSRC, src), os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'mts.h')]
+    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(HERE, '..', 'include', 'mts.h')]
     if any(_newer(d, obj) for d in deps):
         cmd = ['hipcc', *FLAGS, '-c', os.path.join(CSRC, src), '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -19,120 +19,8 @@
 #include <stdlib.h>
 #include "common.h"
 
-struct GemmArgs {
-  const void* A; const void* B; void* C;
-  const float* bias; const void* residual; void* aux;
-  int M, N, K;
-  int lda, ldb, ldc, ldr, ldaux;
-  unsigned epi;
-  float colscale; int ncols_scaled;
-  int ksplit;      // K elements per blockIdx.z slice (multiple of 64)
-  float* slab;     // split-K: slice z stores its fp32 partial tile to slab[z][M][N] (plain stores); reduced afterwards
-};
+#include "gemm_common.h"
 
-// ------------------------------------------------------------------------------------------------
-// shared epilogue: lane owns C[m][n..n+3]
-// ------------------------------------------------------------------------------------------------
-template <typename TA, typename TC>
-__device__ __forceinline__ void epilogue4(const GemmArgs& a, int m, int n, float (&v)[4], bool first_slice) {
-  if (m >= a.M || n >= a.N) return;
-  const unsigned epi = a.epi;
-  const bool full = (n + 3 < a.N);
-  if (full) {
-    if ((epi & MTS_EPI_BIAS) && first_slice) {
-      const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
-      v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-    }
-    if (epi & MTS_EPI_COLSCALE) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) if (n + i < a.ncols_scaled) v[i] *= a.colscale;
-    }
-    if ((epi & MTS_EPI_RESIDUAL) && first_slice) {
-      float r[4];
-      load4<TA>(reinterpret_cast<const TA*>(a.residual) + (size_t)m * a.ldr + n, r);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] += r[i];
-    }
-    if (epi & MTS_EPI_GELU) {
-      if (a.aux) store4<TA>(reinterpret_cast<TA*>(a.aux) + (size_t)m * a.ldaux + n, v);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = gelu_erf_f(v[i]);
-    }
-    TC* c = reinterpret_cast<TC*>(a.C) + (size_t)m * a.ldc + n;
-    if constexpr (sizeof(TC) == 4) {
-      float* cf = reinterpret_cast<float*>(c);
-      if (a.slab) {
-        store4<float>(a.slab + ((size_t)blockIdx.z * a.M + m) * a.N + n, v);
-      } else if (epi & MTS_EPI_ACCUM) {
-        float o[4];
-        load4<float>(cf, o);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] += v[i];
-        store4<float>(cf, o);
-      } else {
-        store4<float>(cf, v);
-      }
-    } else {
-      store4<TC>(c, v);
-    }
-  } else {
-    for (int i = 0; i < 4 && n + i < a.N; ++i) {
-      float x = v[i];
-      if ((epi & MTS_EPI_BIAS) && first_slice) x += a.bias[n + i];
-      if ((epi & MTS_EPI_COLSCALE) && n + i < a.ncols_scaled) x *= a.colscale;
-      if ((epi & MTS_EPI_RESIDUAL) && first_slice) x += to_f32(reinterpret_cast<const TA*>(a.residual)[(size_t)m * a.ldr + n + i]);
-      if (epi & MTS_EPI_GELU) {
-        if (a.aux) reinterpret_cast<TA*>(a.aux)[(size_t)m * a.ldaux + n + i] = from_f32<TA>(x);
-        x = gelu_erf_f(x);
-      }
-      TC* c = reinterpret_cast<TC*>(a.C) + (size_t)m * a.ldc + n + i;
-      if constexpr (sizeof(TC) == 4) {
-        float* cf = reinterpret_cast<float*>(c);
-        if (a.slab) a.slab[((size_t)blockIdx.z * a.M + m) * a.N + n + i] = x;
-        else if (epi & MTS_EPI_ACCUM) *cf += x;
-        else *cf = x;
-      } else {
-        *c = from_f32<TC>(x);
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// bf16 MFMA kernel
-// ------------------------------------------------------------------------------------------------
-#define BM 128
-#define BN 128
-#define BK 64
-#define TILE_BYTES (128 * 64 * 2)  // one operand stage = 16 KiB in either image
-
-// K-major image: [128 rows][64 k] bf16, 128-B rows, 16-B chunk index XORed with (row>>1)&7.
-__device__ __forceinline__ int kmajor_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-// strided image: [64 k-rows][128 cols] bf16, 256-B rows, 32-B chunk index XORed with key(krow).
-__device__ __forceinline__ int strided_key(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
-__device__ __forceinline__ int strided_off(int krow, int col) {
-  return krow * 256 + ((((col >> 4) ^ strided_key(krow))) << 5) + ((col & 15) << 1);
-}
-
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-
-__device__ __forceinline__ bf16x8 frag_kmajor(const char* tile, int row, int chunk) {
-  return *reinterpret_cast<const bf16x8*>(tile + kmajor_off(row, chunk));
-}
-// fragment X[k = kbase + 0..7][c = c0 + (lane&15)] of a strided image through two transposed reads
-__device__ __forceinline__ bf16x8 frag_strided(const char* tile, int kbase, int c0, int lane) {
-  const int r = lane & 15;
-  const int q = r >> 2, p = r & 3;
-  const int col = c0 + 4 * p;
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + strided_off(kbase + q, col)));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + strided_off(kbase + 4 + q, col)));
-  typedef __attribute__((ext_vector_type(8))) short s16x8;
-  s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-  return __builtin_bit_cast(bf16x8, v);
-}
-
-typedef __attribute__((address_space(1))) const void gptr_t;
-typedef __attribute__((address_space(3))) void lptr_t;
 
 // GLDS = true: both operands go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write
 // instructions -- the ds_write_b128 pass of the register-staged form costs about as many LDS cycles as all the
@@ -470,7 +358,21 @@ extern "C" int mts_cast(void* stream, int dst_dtype, const float* src, void* dst
   return MTS_OK;
 }
 
-static int g_gemm_glds = -1;   // MTS_GEMM_GLDS=0 forces the register-staged form (A/B testing)
+int mts_launch_gemm256(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st);   // gemm256.hip
+
+static int g_gemm_glds = -1;
+static int g_tile_mode = -1;
+static int g_force_splits = 0;
+
+extern "C" int mts_set_option(const char* key, int value) {
+  if (!key) return MTS_ERR_INVALID;
+  if (!strcmp(key, "gemm_tile")) { g_tile_mode = value; return MTS_OK; }
+  if (!strcmp(key, "gemm_glds")) { g_gemm_glds = value; return MTS_OK; }
+  if (!strcmp(key, "gemm_splits")) { g_force_splits = value; return MTS_OK; }
+  mts_set_error("mts_set_option: unknown key %s", key);
+  return MTS_ERR_INVALID;
+}
+   // MTS_GEMM_GLDS=0 forces the register-staged form (A/B testing)
 
 template <int LAYOUT, typename TC>
 static void launch_bf16(const GemmArgs& a, int splits, hipStream_t st) {
@@ -524,23 +426,39 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
   MTS_UNSUPPORTED(!(epilogue & MTS_EPI_RESIDUAL) || (ldr % 4 == 0 && ((uintptr_t)residual % 8) == 0), "mts_gemm(bf16): residual alignment");
   MTS_UNSUPPORTED(!aux || (ldaux % 4 == 0 && ((uintptr_t)aux % 8) == 0), "mts_gemm(bf16): aux alignment");
 
-  // Split-K for weight-gradient shapes (few output tiles, K = all tokens): pick the split that minimises
-  // rounds-of-workgroups x K/split + the slab round trip; partial tiles go to `workspace` with plain stores and a
-  // second kernel sums them in a fixed order (no float atomics: deterministic, and 4-5x the atomic byte rate).
-  int splits = 1;
+  // Plan: tile size (128x128, 2 workgroups per CU  vs  256x256, 1 per CU, deeper DMA pipeline) and, for weight-gradient
+  // shapes (fp32 C, no epilogue, K = all tokens), the K split.  Cost model = rounds of workgroups x K per slice x
+  // measured time per K element + the slab round trip; partial tiles go to `workspace` with plain stores and a second
+  // kernel sums them in a fixed order (no float atomics: deterministic, and several times the atomic byte rate).
+  if (g_tile_mode < 0) {       // MTS_GEMM_TILE=128|256 forces one kernel (A/B testing); default: cost model
+    const char* e = getenv("MTS_GEMM_TILE");
+    g_tile_mode = e ? atoi(e) : 0;
+  }
+  const int tile_mode = g_tile_mode;
   const unsigned plain = epilogue & ~MTS_EPI_ACCUM;
-  if (c_dtype == MTS_F32 && plain == 0 && workspace && N % 4 == 0 && K >= 2048) {
-    const int nt = ceil_div(M, BM) * ceil_div(N, BN);
-    const double slots = 512.0, t_k = 0.021, bw = 3500.0;   // us per K element per round; slab MB per us ~ 3.5 TB/s
-    double best = 1e30;
-    for (int sp = 1; sp <= 32; ++sp) {
+  const bool can_split = (c_dtype == MTS_F32 && plain == 0 && workspace && N % 4 == 0 && K >= 2048);
+  // 256-tile kernel: K-contiguous A only (its transposed-read TN form measures slower than the 128 kernel)
+  const bool can256 = (K % BK == 0) && K >= 512 && M >= 8 && N >= 8 && tile_mode != 128 && (layout != MTS_TN || tile_mode == 256);
+  const double bw = 3500.0;     // slab MB per us
+  double best = 1e30;
+  int splits = 1;
+  bool use256 = false;
+  for (int big = 0; big <= (can256 ? 1 : 0); ++big) {
+    if (tile_mode == 256 && can256 && !big) continue;
+    const int tile = big ? 256 : 128;
+    // measured on MI355X (tools/gemm_ksweep.py, gemm_sweep.py): us per K element per round of workgroups, and per-round fixed cost
+    const double slots = big ? 256.0 : 512.0;
+    const double t_k = big ? (layout == MTS_TN ? 0.0353 : 0.0232) : (layout == MTS_TN ? 0.0170 : 0.0180);
+    const double t_0 = big ? 7.7 : 6.5;
+    const int nt = ceil_div(M, tile) * ceil_div(N, tile);
+    for (int sp = 1; sp <= (can_split ? 32 : 1); ++sp) {
       const int ks = ceil_div(ceil_div(K, sp), BK) * BK;
-      const int real = ceil_div(K, ks);
-      if (real != sp) continue;
+      if (ceil_div(K, ks) != sp) continue;
       if (sp > 1 && (size_t)sp * M * N * sizeof(float) > workspace_bytes) break;
+      if (g_force_splits > 0 && can_split && sp != g_force_splits) continue;
       const double rounds = ceil((double)nt * sp / slots);
-      const double cost = rounds * ks * t_k + (sp > 1 ? (2.0 * sp + 1.0) * M * N * 4.0 / 1e6 / bw : 0.0);
-      if (cost < best) { best = cost; splits = sp; }
+      const double cost = rounds * (ks * t_k + t_0) + (sp > 1 ? (2.0 * sp + 1.0) * M * N * 4.0 / 1e6 / bw : 0.0);
+      if (cost < best) { best = cost; splits = sp; use256 = big; }
     }
   }
   a.slab = nullptr;
@@ -548,7 +466,10 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
     a.ksplit = ceil_div(ceil_div(K, splits), BK) * BK;
     a.slab = (float*)workspace;
   }
-  if (c_dtype == MTS_F32) {
+  if (use256) {
+    int rc = mts_launch_gemm256(a, layout, c_dtype == MTS_F32, splits, st);
+    if (rc) return rc;
+  } else if (c_dtype == MTS_F32) {
     if (layout == MTS_NT) launch_bf16<MTS_NT, float>(a, splits, st);
     else if (layout == MTS_NN) launch_bf16<MTS_NN, float>(a, splits, st);
     else launch_bf16<MTS_TN, float>(a, splits, st);

@@ -1,0 +1,144 @@
+// Pieces shared by the two bf16 MFMA GEMM kernels (gemm.hip: 128x128 tile; gemm256.hip: 256x256 tile).
+#pragma once
+#include "common.h"
+
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+struct GemmArgs {
+  const void* A; const void* B; void* C;
+  const float* bias; const void* residual; void* aux;
+  int M, N, K;
+  int lda, ldb, ldc, ldr, ldaux;
+  unsigned epi;
+  float colscale; int ncols_scaled;
+  int ksplit;      // K elements per blockIdx.z slice (multiple of 64)
+  float* slab;     // split-K: slice z stores its fp32 partial tile to slab[z][M][N] (plain stores); reduced afterwards
+};
+
+// ------------------------------------------------------------------------------------------------
+// shared epilogue: lane owns C[m][n..n+3]
+// ------------------------------------------------------------------------------------------------
+// epilogue arithmetic only (bias, q-scale, residual, GELU + pre-activation) for 4 consecutive in-range columns
+template <typename TA>
+__device__ __forceinline__ void epi_math4(const GemmArgs& a, int m, int n, float (&v)[4], bool first_slice) {
+  const unsigned epi = a.epi;
+  if ((epi & MTS_EPI_BIAS) && first_slice) {
+    const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+  }
+  if (epi & MTS_EPI_COLSCALE) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (n + i < a.ncols_scaled) v[i] *= a.colscale;
+  }
+  if ((epi & MTS_EPI_RESIDUAL) && first_slice) {
+    float r[4];
+    load4<TA>(reinterpret_cast<const TA*>(a.residual) + (size_t)m * a.ldr + n, r);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += r[i];
+  }
+  if (epi & MTS_EPI_GELU) {
+    if (a.aux) store4<TA>(reinterpret_cast<TA*>(a.aux) + (size_t)m * a.ldaux + n, v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = gelu_erf_f(v[i]);
+  }
+}
+
+template <typename TA, typename TC>
+__device__ __forceinline__ void epilogue4(const GemmArgs& a, int m, int n, float (&v)[4], bool first_slice) {
+  if (m >= a.M || n >= a.N) return;
+  const unsigned epi = a.epi;
+  const bool full = (n + 3 < a.N);
+  if (full) {
+    if ((epi & MTS_EPI_BIAS) && first_slice) {
+      const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+      v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if (epi & MTS_EPI_COLSCALE) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) if (n + i < a.ncols_scaled) v[i] *= a.colscale;
+    }
+    if ((epi & MTS_EPI_RESIDUAL) && first_slice) {
+      float r[4];
+      load4<TA>(reinterpret_cast<const TA*>(a.residual) + (size_t)m * a.ldr + n, r);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += r[i];
+    }
+    if (epi & MTS_EPI_GELU) {
+      if (a.aux) store4<TA>(reinterpret_cast<TA*>(a.aux) + (size_t)m * a.ldaux + n, v);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = gelu_erf_f(v[i]);
+    }
+    TC* c = reinterpret_cast<TC*>(a.C) + (size_t)m * a.ldc + n;
+    if constexpr (sizeof(TC) == 4) {
+      float* cf = reinterpret_cast<float*>(c);
+      if (a.slab) {
+        store4<float>(a.slab + ((size_t)blockIdx.z * a.M + m) * a.N + n, v);
+      } else if (epi & MTS_EPI_ACCUM) {
+        float o[4];
+        load4<float>(cf, o);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] += v[i];
+        store4<float>(cf, o);
+      } else {
+        store4<float>(cf, v);
+      }
+    } else {
+      store4<TC>(c, v);
+    }
+  } else {
+    for (int i = 0; i < 4 && n + i < a.N; ++i) {
+      float x = v[i];
+      if ((epi & MTS_EPI_BIAS) && first_slice) x += a.bias[n + i];
+      if ((epi & MTS_EPI_COLSCALE) && n + i < a.ncols_scaled) x *= a.colscale;
+      if ((epi & MTS_EPI_RESIDUAL) && first_slice) x += to_f32(reinterpret_cast<const TA*>(a.residual)[(size_t)m * a.ldr + n + i]);
+      if (epi & MTS_EPI_GELU) {
+        if (a.aux) reinterpret_cast<TA*>(a.aux)[(size_t)m * a.ldaux + n + i] = from_f32<TA>(x);
+        x = gelu_erf_f(x);
+      }
+      TC* c = reinterpret_cast<TC*>(a.C) + (size_t)m * a.ldc + n + i;
+      if constexpr (sizeof(TC) == 4) {
+        float* cf = reinterpret_cast<float*>(c);
+        if (a.slab) a.slab[((size_t)blockIdx.z * a.M + m) * a.N + n + i] = x;
+        else if (epi & MTS_EPI_ACCUM) *cf += x;
+        else *cf = x;
+      } else {
+        *c = from_f32<TC>(x);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 MFMA kernel
+// ------------------------------------------------------------------------------------------------
+#define BM 128
+#define BN 128
+#define BK 64
+#define TILE_BYTES (128 * 64 * 2)  // one operand stage = 16 KiB in either image
+
+// K-major image: [128 rows][64 k] bf16, 128-B rows, 16-B chunk index XORed with (row>>1)&7.
+__device__ __forceinline__ int kmajor_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// strided image: [64 k-rows][128 cols] bf16, 256-B rows, 32-B chunk index XORed with key(krow).
+__device__ __forceinline__ int strided_key(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
+__device__ __forceinline__ int strided_off(int krow, int col) {
+  return krow * 256 + ((((col >> 4) ^ strided_key(krow))) << 5) + ((col & 15) << 1);
+}
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ bf16x8 frag_kmajor(const char* tile, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8*>(tile + kmajor_off(row, chunk));
+}
+// fragment X[k = kbase + 0..7][c = c0 + (lane&15)] of a strided image through two transposed reads
+__device__ __forceinline__ bf16x8 frag_strided(const char* tile, int kbase, int c0, int lane) {
+  const int r = lane & 15;
+  const int q = r >> 2, p = r & 3;
+  const int col = c0 + 4 * p;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + strided_off(kbase + q, col)));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + strided_off(kbase + 4 + q, col)));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+

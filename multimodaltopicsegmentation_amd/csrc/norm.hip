@@ -386,33 +386,6 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ dp
   for (int j = 0; j < 4; ++j) cur[j] += s[j];
   store4<float>(o, cur);
 }
-// dtype0[e] += sum_i rowsums[i][e], rowsums = the rows of dpos just written minus their previous content is
-// not recoverable, so the sum is taken over dpre directly (second pass over L rows of per-position sums kept
-// in `scratch` [L, D]).
-template <typename T>
-__global__ __launch_bounds__(256) void embed_bwd_type_kernel(const T* __restrict__ dpre, int rows, int D, float* __restrict__ partial) {
-  // grid: (ceil(D/4/256), 64 row slices) -> partial[slice][D]
-  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (e >= D) return;
-  const int per = (rows + gridDim.y - 1) / gridDim.y;
-  const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
-  float s[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int r = r0; r < r1; ++r) {
-    float v[4];
-    load4<T>(dpre + (size_t)r * D + e, v);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) s[j] += v[j];
-  }
-  store4<float>(partial + (size_t)blockIdx.y * D + e, s);
-}
-__global__ __launch_bounds__(256) void embed_bwd_type_final(const float* __restrict__ partial, int nparts, int D, float* __restrict__ dtype0) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= D) return;
-  float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * D + e];
-  dtype0[e] += s;
-}
-
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -522,24 +495,13 @@ extern "C" int mts_layernorm_bwd(void* stream, int dtype, int rows, int D, const
   return MTS_ERR_INVALID;
 }
 
-extern "C" int mts_embed_bwd(void* stream, int dtype, int B, int L, int D, const void* dpre, float* dpos, int pos_offset, float* dtype0,
-                             void* partial) {
-  MTS_CHECK_ARG(B > 0 && L > 0 && D > 0 && D % 4 == 0 && dpre && dpos && dtype0 && partial, "mts_embed_bwd: bad arguments");
+extern "C" int mts_embed_bwd(void* stream, int dtype, int B, int L, int D, const void* dpre, float* dpos, int pos_offset) {
+  MTS_CHECK_ARG(B > 0 && L > 0 && D > 0 && D % 4 == 0 && dpre && dpos, "mts_embed_bwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   const int blocks = (int)(((size_t)L * (D / 4) + 255) / 256);
-  const int slices = 64;
-  dim3 g2(ceil_div(D / 4, 256), slices);
-  if (dtype == MTS_F32) {
-    hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dpre, B, L, D, dpos, pos_offset);
-    hipLaunchKernelGGL(embed_bwd_type_kernel<float>, g2, dim3(256), 0, st, (const float*)dpre, B * L, D, (float*)partial);
-  } else if (dtype == MTS_BF16) {
-    hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dpre, B, L, D, dpos, pos_offset);
-    hipLaunchKernelGGL(embed_bwd_type_kernel<bf16_t>, g2, dim3(256), 0, st, (const bf16_t*)dpre, B * L, D, (float*)partial);
-  } else {
-    mts_set_error("mts_embed_bwd: bad dtype %d", dtype);
-    return MTS_ERR_INVALID;
-  }
-  hipLaunchKernelGGL(embed_bwd_type_final, dim3(ceil_div(D, 256)), dim3(256), 0, st, (const float*)partial, slices, D, dtype0);
+  if (dtype == MTS_F32) hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dpre, B, L, D, dpos, pos_offset);
+  else if (dtype == MTS_BF16) hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dpre, B, L, D, dpos, pos_offset);
+  else { mts_set_error("mts_embed_bwd: bad dtype %d", dtype); return MTS_ERR_INVALID; }
   MTS_LAUNCH_CHECK("mts_embed_bwd");
   return MTS_OK;
 }

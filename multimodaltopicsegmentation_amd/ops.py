@@ -133,10 +133,9 @@ def layernorm_bwd(x, dy, gamma, mean, rstd, dx, dgamma, dbeta, dxsum=None, dlogi
                                 ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(dxsum), ptr(ws)))
 
 
-def embed_bwd(dpre, B, Lq, dpos, pos_offset, dtype0):
+def embed_bwd(dpre, B, Lq, dpos, pos_offset):
     D = dpre.shape[-1]
-    ws = _scratch(64 * D * 4, dpre.device, 'embed_bwd')
-    check(lib.mts_embed_bwd(stream_ptr(), dtype_code(dpre.dtype), B, Lq, D, ptr(dpre), ptr(dpos), pos_offset, ptr(dtype0), ptr(ws)))
+    check(lib.mts_embed_bwd(stream_ptr(), dtype_code(dpre.dtype), B, Lq, D, ptr(dpre), ptr(dpos), pos_offset))
 
 
 def gelu_bwd(u, dy):

@@ -363,11 +363,12 @@ class Transformer_segmenter(_TaggerBase):
             dh = dhin
         e = 'model.model.embeddings.'
         dpre = ws.get('ds2', N, D, dt, dev)
-        ops.layernorm_bwd(st['pre0'], dh, self._w(pf, e + 'LayerNorm.weight'), st['mean0'], st['rstd0'], dpre,
-                          G(e + 'LayerNorm.weight'), G(e + 'LayerNorm.bias'))
-        G(e + 'position_embeddings.weight').zero_()
         G(e + 'token_type_embeddings.weight').zero_()
-        ops.embed_bwd(dpre, B, Lq, G(e + 'position_embeddings.weight'), 2, G(e + 'token_type_embeddings.weight')[0])
+        # d(type row 0) = sum over all rows of dpre = the LayerNorm backward's column sum of dx
+        ops.layernorm_bwd(st['pre0'], dh, self._w(pf, e + 'LayerNorm.weight'), st['mean0'], st['rstd0'], dpre,
+                          G(e + 'LayerNorm.weight'), G(e + 'LayerNorm.bias'), dxsum=G(e + 'token_type_embeddings.weight')[0])
+        G(e + 'position_embeddings.weight').zero_()
+        ops.embed_bwd(dpre, B, Lq, G(e + 'position_embeddings.weight'), 2)
 
     # ---- public API ------------------------------------------------------------------------------------
     def loss_and_grad(self, xs, lengths, tags, want_grad=True):
