@@ -277,11 +277,19 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
 }
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int N, int nparts,
                                                            float* __restrict__ out, int accumulate) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
+  // 64 columns x 4 groups of partial rows per workgroup; fixed-order LDS combine
+  __shared__ float red[4][64];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + col;
   float s = 0.f;
-  for (int r = 0; r < nparts; ++r) s += partial[(size_t)r * N + n];
-  out[n] = accumulate ? out[n] + s : s;
+  if (n < N)
+    for (int r = grp; r < nparts; r += 4) s += partial[(size_t)r * N + n];
+  red[grp][col] = s;
+  __syncthreads();
+  if (grp == 0 && n < N) {
+    const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+    out[n] = accumulate ? out[n] + t : t;
+  }
 }
 
 // C[m,n] (+)= sum_z slab[z][m][n]  -- fixed summation order, so split-K weight gradients are bitwise reproducible
@@ -335,7 +343,7 @@ extern "C" int mts_colsum(void* stream, int dtype, int M, int N, const void* X, 
     hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, st, (const float*)X, M, N, ldx, (float*)partial);
   else
     hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)X, M, N, ldx, (float*)partial);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, (const float*)partial, N, COLSUM_RS, out,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(N, 64)), dim3(256), 0, st, (const float*)partial, N, COLSUM_RS, out,
                      accumulate);
   MTS_LAUNCH_CHECK("mts_colsum");
   return MTS_OK;

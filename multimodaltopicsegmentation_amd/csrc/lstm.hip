@@ -206,12 +206,22 @@ __global__ void transpose_f32_kernel(const float* __restrict__ src, float* __res
     if (x < rows && y + i < cols) dd[(size_t)(y + i) * rows + x] = tile[threadIdx.x][threadIdx.y + i];
 }
 
+// MFMA fast path (lstm_mfma.hip): bf16, H = 256
+bool mts_lstm_mfma_supported(int dtype, int H);
+size_t mts_lstm_mfma_workspace(int H, int ndir);
+int mts_lstm_mfma_fwd(hipStream_t st, int B, int L, int H, int ndir, const void* xproj, const float* w_hh, const float* b_hh,
+                      const int32_t* lengths, void* out, void* gates, float* cells, void* ws);
+int mts_lstm_mfma_bwd(hipStream_t st, int B, int L, int H, int ndir, const float* w_hh, const int32_t* lengths, const void* out, const void* gates,
+                      const float* cells, const void* dout, void* dxproj, void* hprev, void* ws);
+static int g_lstm_mfma = 1;
+extern "C" void mts_lstm_set_mfma(int on) { g_lstm_mfma = on; }
+
 static int lstm_threads(int H) { return ((H + 63) / 64) * 64; }
 
 // workspace: fwd needs W_hh^T (fp32 [ndir,H,4H]); bwd needs hprev (act dtype [B*L, ndir*H])
 extern "C" size_t mts_lstm_workspace(int dtype, int B, int L, int H, int ndir) {
   const size_t esz = dtype == MTS_F32 ? 4 : 2;
-  const size_t a = align_up((size_t)ndir * 4 * H * H * sizeof(float), 256);
+  const size_t a = std::max(align_up((size_t)ndir * 4 * H * H * sizeof(float), 256), mts_lstm_mfma_workspace(H, ndir));
   const size_t b = align_up((size_t)B * L * ndir * H * esz, 256);
   return a + b;
 }
@@ -223,6 +233,8 @@ extern "C" int mts_lstm_fwd(void* stream, int dtype, int B, int L, int H, int nd
   MTS_CHECK_ARG(dtype == MTS_F32 || dtype == MTS_BF16, "mts_lstm_fwd: bad dtype %d", dtype);
   MTS_UNSUPPORTED(H <= 1024, "mts_lstm_fwd: hidden size %d > 1024", H);
   hipStream_t st = (hipStream_t)stream;
+  if (g_lstm_mfma && mts_lstm_mfma_supported(dtype, H))
+    return mts_lstm_mfma_fwd(st, B, L, H, ndir, xproj, w_hh, b_hh, lengths, out, gates, cells, workspace);
   float* whhT = (float*)workspace;
   hipLaunchKernelGGL(transpose_f32_kernel, dim3(ceil_div(H, 32), ceil_div(4 * H, 32), ndir), dim3(32, 8), 0, st, w_hh, whhT, 4 * H, H);
   const size_t lds = (size_t)2 * LSTM_DG * H * sizeof(float);
@@ -242,11 +254,18 @@ extern "C" int mts_lstm_bwd(void* stream, int dtype, int B, int L, int H, int nd
   MTS_CHECK_ARG(dtype == MTS_F32 || dtype == MTS_BF16, "mts_lstm_bwd: bad dtype %d", dtype);
   MTS_UNSUPPORTED(H <= 1024, "mts_lstm_bwd: hidden size %d > 1024", H);
   hipStream_t st = (hipStream_t)stream;
-  char* hprev = (char*)workspace + align_up((size_t)ndir * 4 * H * H * sizeof(float), 256);
+  char* hprev = (char*)workspace + std::max(align_up((size_t)ndir * 4 * H * H * sizeof(float), 256), mts_lstm_mfma_workspace(H, ndir));
+  const bool fast = g_lstm_mfma && mts_lstm_mfma_supported(dtype, H);
+  if (fast) {
+    int rc = mts_lstm_mfma_bwd(st, B, L, H, ndir, w_hh, lengths, out, gates, cells, dout, dxproj, hprev, workspace);
+    if (rc) return rc;
+  }
   const size_t lds = (size_t)LSTM_DG * 4 * H * sizeof(float);
   MTS_UNSUPPORTED(lds <= 160 * 1024, "mts_lstm_bwd: hidden size %d needs too much LDS", H);
   dim3 grid(ceil_div(B, LSTM_DG), ndir), block(lstm_threads(H));
-  if (dtype == MTS_F32) {
+  if (fast) {
+    // recurrence done above
+  } else if (dtype == MTS_F32) {
     auto k = lstm_bwd_kernel<float>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, grid, block, lds, st, B, L, H, ndir, w_hh, lengths, (const float*)out, (const float*)gates, cells, (const float*)dout,

@@ -11,7 +11,7 @@
 #include "common.h"
 
 #define ROW_WAVES 4            // waves (= rows in flight) per workgroup
-#define BWD_MAX_BLOCKS 256
+#define BWD_MAX_BLOCKS 512
 
 template <typename T, int NV> struct RowRegs {
   float v[NV][4];

@@ -312,7 +312,8 @@ def test_tagger_loss_rejects_unknown_kind(ops):
 
 # ------------------------------------------------------------------------------------------------ LSTM
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('B,Lq,H,lengths', [(5, 19, 32, [19, 11, 1, 7, 19]), (9, 12, 24, [12, 3, 5, 12, 1, 2, 8, 9, 4])])
+@pytest.mark.parametrize('B,Lq,H,lengths', [(5, 19, 32, [19, 11, 1, 7, 19]), (9, 12, 24, [12, 3, 5, 12, 1, 2, 8, 9, 4]),
+                                            (20, 10, 256, [10, 3, 5, 10, 1, 2, 8, 9, 4, 7, 10, 6, 2, 9, 1, 10, 3, 10, 5, 8])])   # H=256: MFMA path in bf16
 def test_lstm_fwd_bwd(ops, dtype, B, Lq, H, lengths):
     N = B * Lq
     xproj = _rnd(N, 8 * H, seed=34).to(dtype)
