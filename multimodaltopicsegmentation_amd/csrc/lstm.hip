@@ -213,6 +213,13 @@ int mts_lstm_mfma_fwd(hipStream_t st, int B, int L, int H, int ndir, const void*
                       const int32_t* lengths, void* out, void* gates, float* cells, void* ws);
 int mts_lstm_mfma_bwd(hipStream_t st, int B, int L, int H, int ndir, const float* w_hh, const int32_t* lengths, const void* out, const void* gates,
                       const float* cells, const void* dout, void* dxproj, void* hprev, void* ws);
+// CU-pair form (lstm_pair.hip): weights fully register-resident, forward only so far
+bool mts_lstm_pair_supported(int dtype, int H);
+size_t mts_lstm_pair_workspace(int B, int H, int ndir);
+int mts_lstm_pair_fwd(hipStream_t st, int B, int L, int H, int ndir, const void* xproj, const float* w_hh, const float* b_hh,
+                      const int32_t* lengths, void* out, void* gates, float* cells, void* ws);
+int mts_lstm_pair_bwd(hipStream_t st, int B, int L, int H, int ndir, const float* w_hh, const int32_t* lengths, const void* out, const void* gates,
+                      const float* cells, const void* dout, void* dxproj, void* hprev, void* ws);
 static int g_lstm_mfma = 1;
 extern "C" void mts_lstm_set_mfma(int on) { g_lstm_mfma = on; }
 
@@ -221,7 +228,8 @@ static int lstm_threads(int H) { return ((H + 63) / 64) * 64; }
 // workspace: fwd needs W_hh^T (fp32 [ndir,H,4H]); bwd needs hprev (act dtype [B*L, ndir*H])
 extern "C" size_t mts_lstm_workspace(int dtype, int B, int L, int H, int ndir) {
   const size_t esz = dtype == MTS_F32 ? 4 : 2;
-  const size_t a = std::max(align_up((size_t)ndir * 4 * H * H * sizeof(float), 256), mts_lstm_mfma_workspace(H, ndir));
+  size_t a = std::max(align_up((size_t)ndir * 4 * H * H * sizeof(float), 256), mts_lstm_mfma_workspace(H, ndir));
+  a = std::max(a, align_up(mts_lstm_pair_workspace(B, H, ndir), 256));
   const size_t b = align_up((size_t)B * L * ndir * H * esz, 256);
   return a + b;
 }
@@ -233,6 +241,8 @@ extern "C" int mts_lstm_fwd(void* stream, int dtype, int B, int L, int H, int nd
   MTS_CHECK_ARG(dtype == MTS_F32 || dtype == MTS_BF16, "mts_lstm_fwd: bad dtype %d", dtype);
   MTS_UNSUPPORTED(H <= 1024, "mts_lstm_fwd: hidden size %d > 1024", H);
   hipStream_t st = (hipStream_t)stream;
+  if (g_lstm_mfma && mts_lstm_pair_supported(dtype, H))
+    return mts_lstm_pair_fwd(st, B, L, H, ndir, xproj, w_hh, b_hh, lengths, out, gates, cells, workspace);
   if (g_lstm_mfma && mts_lstm_mfma_supported(dtype, H))
     return mts_lstm_mfma_fwd(st, B, L, H, ndir, xproj, w_hh, b_hh, lengths, out, gates, cells, workspace);
   float* whhT = (float*)workspace;
@@ -254,10 +264,14 @@ extern "C" int mts_lstm_bwd(void* stream, int dtype, int B, int L, int H, int nd
   MTS_CHECK_ARG(dtype == MTS_F32 || dtype == MTS_BF16, "mts_lstm_bwd: bad dtype %d", dtype);
   MTS_UNSUPPORTED(H <= 1024, "mts_lstm_bwd: hidden size %d > 1024", H);
   hipStream_t st = (hipStream_t)stream;
-  char* hprev = (char*)workspace + std::max(align_up((size_t)ndir * 4 * H * H * sizeof(float), 256), mts_lstm_mfma_workspace(H, ndir));
-  const bool fast = g_lstm_mfma && mts_lstm_mfma_supported(dtype, H);
+  size_t hoff = std::max(align_up((size_t)ndir * 4 * H * H * sizeof(float), 256), mts_lstm_mfma_workspace(H, ndir));
+  hoff = std::max(hoff, align_up(mts_lstm_pair_workspace(B, H, ndir), 256));
+  char* hprev = (char*)workspace + hoff;
+  const bool fast = g_lstm_mfma && (mts_lstm_mfma_supported(dtype, H) || mts_lstm_pair_supported(dtype, H));
   if (fast) {
-    int rc = mts_lstm_mfma_bwd(st, B, L, H, ndir, w_hh, lengths, out, gates, cells, dout, dxproj, hprev, workspace);
+    int rc = mts_lstm_pair_supported(dtype, H)
+                 ? mts_lstm_pair_bwd(st, B, L, H, ndir, w_hh, lengths, out, gates, cells, dout, dxproj, hprev, workspace)
+                 : mts_lstm_mfma_bwd(st, B, L, H, ndir, w_hh, lengths, out, gates, cells, dout, dxproj, hprev, workspace);
     if (rc) return rc;
   }
   const size_t lds = (size_t)LSTM_DG * 4 * H * sizeof(float);

@@ -1,0 +1,569 @@
+// LSTM recurrence, "CU pair" form (bf16, H = 256): W_hh fully resident in registers.
+//
+// Measured on MI355X (tools/lstm_bench.py, MTS_LSTM_EXP ablations): with one workgroup per (16 documents, direction)
+// the recurrent matrix (512 KiB bf16) does not fit a CU and re-streaming even half of it from L2 costs ~5.7 us of a
+// 10.6 us step (a CU pulls only ~45 GB/s through fragment-shaped loads).  So the hidden units of one direction are
+// split over TWO workgroups (half p = 0/1, 128 units each, 8 waves = two per SIMD so that one wave's gate math
+// overlaps the other's MFMAs): wave w keeps the 4 gate tiles x 8 k-steps of its 16 units (128 VGPRs) for the whole
+// sequence and there is NO weight traffic in the time loop.  What the pair exchanges per step is the new h of its
+// half (16 docs x 128 units bf16 = 4 KiB) as 8-byte {tag = step+1, 2 x bf16} granules written with agent-scope
+// atomic stores and polled with agent-scope atomic loads (the data is its own flag: no fence, no separate flag
+// word; cdna guide G16/R2).  Each pair serves TWO groups of 16 documents alternately, so a group's exchange latency
+// is covered by the other group's compute.
+//
+// Safety: both workgroups of a pair are co-resident by construction (the grid is a few dozen workgroups at most);
+// every spin is bounded and a timeout sets a status word instead of hanging; the exchange buffer is zeroed by a
+// memset node before every launch; tags count steps within the call.  Placement (pair members 8 block ids apart =
+// same XCD under round-robin dispatch) is a speed hint only.
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+
+#define LP_DOCS 16
+#define LP_GROUPS 2
+#define LP_SPIN_LIMIT (1u << 22)
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ float fsig2(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float ftanh2(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
+__device__ __forceinline__ uint2 pk4(const float (&v)[4]) { return make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])); }
+__device__ __forceinline__ void upk4(const uint2& u, float (&v)[4]) { v[0] = bf16_lo(u.x); v[1] = bf16_hi(u.x); v[2] = bf16_lo(u.y); v[3] = bf16_hi(u.y); }
+
+// packed weights: wpk[d][p][w][gate][ks][lane] = 8 bf16 = the MFMA A fragment (row = gate column, k) wave w of half p needs
+__global__ void lstm_pack_weights_kernel(const float* __restrict__ w_hh, bf16_t* __restrict__ wpk, int H, int ndir) {
+  const int KS = H / 32, NW = H / 32;                                  // waves per half = (H/2)/16
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // over d, p, w, gate, ks, lane
+  const size_t total = (size_t)ndir * 2 * NW * 4 * KS * 64;
+  if (idx >= total) return;
+  const int lane = idx % 64;
+  size_t r = idx / 64;
+  const int ks = r % KS; r /= KS;
+  const int gt = r % 4; r /= 4;
+  const int w = r % NW; r /= NW;
+  const int p = r % 2; r /= 2;
+  const int d = (int)r;
+  const int col = gt * H + p * (H / 2) + w * 16 + (lane & 15);
+  const int k = ks * 32 + 8 * (lane >> 4);
+  const float* src = w_hh + ((size_t)d * 4 * H + col) * H + k;
+  bf16_t* dst = wpk + idx * 8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dst[j] = (bf16_t)src[j];
+}
+
+template <int KS>
+__global__ __launch_bounds__(KS * 64, 2) void lstm_fwd_pair_kernel(int B, int L, int ndir, int npairs, const bf16_t* __restrict__ xproj,
+                                                                   const bf16_t* __restrict__ wpk, const float* __restrict__ bhh,
+                                                                   const int32_t* __restrict__ lengths, bf16_t* __restrict__ out,
+                                                                   bf16_t* __restrict__ gates, float* __restrict__ cells, u64* __restrict__ xch,
+                                                                   unsigned* __restrict__ status, int xflags) {
+  constexpr int H = KS * 32;
+  constexpr int HH = H / 2;                              // units per workgroup
+  constexpr int NT = KS * 64;                            // threads
+  constexpr int GPT = 1024 / NT;                         // granules each thread fetches
+  constexpr int HROW = (H + 8) * 2;
+  // xflags (MTS_LSTM_EXP, timing diagnostics only): 1 no gate/cell/out stores, 2 do not wait for the partner, 4 no posts
+  const bool x_nostore = xflags & 1, x_nowait = xflags & 2, x_nopost = xflags & 4;
+  const bool x_nofetch = xflags & 8, x_nomath = xflags & 16, x_nomfma = xflags & 32, x_nobar = xflags & 64, x_nox = xflags & 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* hbuf = smem;                                     // [group][parity][16][HROW]
+  float* blds = reinterpret_cast<float*>(smem + LP_GROUPS * 2 * LP_DOCS * HROW);   // [4][HH] this half's recurrent bias
+  // pair index and half from a 1-D grid: the two halves of a pair are 8 block ids apart
+  const int chunk = blockIdx.x / 16, within = blockIdx.x % 16;
+  const int p = within / 8, pair = chunk * 8 + within % 8;
+  if (pair >= npairs) return;
+  const int gx = pair / ndir, d = pair % ndir;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int doc = lane & 15, g4 = lane >> 4;
+  const int ul = w * 16 + 4 * g4;                        // this lane's 4 units, within the half
+  const int u = p * HH + ul;                             // ... within H
+  const int ldx = ndir * 4 * H, ldo = ndir * H;
+
+  // resident weights: gate tiles i, f, g in registers (96 VGPRs), the o tile in a wave-private LDS area (lane-linear 1 KiB
+  // per k-step: conflict-free) -- all four in registers leaves too few VGPRs for the step's working set and spills
+  bf16x8 wreg[3][KS];
+  char* wl = smem + LP_GROUPS * 2 * LP_DOCS * HROW + 4 * HH * sizeof(float) + (size_t)w * KS * 1024;
+  {
+    const bf16_t* base = wpk + ((((size_t)d * 2 + p) * KS + w) * 4 * KS * 64) * 8;
+#pragma unroll
+    for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) wreg[gt][ks] = *reinterpret_cast<const bf16x8*>(base + ((size_t)(gt * KS + ks) * 64 + lane) * 8);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      *reinterpret_cast<bf16x8*>(wl + ks * 1024 + lane * 16) = *reinterpret_cast<const bf16x8*>(base + ((size_t)(3 * KS + ks) * 64 + lane) * 8);
+  }
+  for (int i = tid; i < 4 * HH; i += NT) blds[i] = bhh ? bhh[(size_t)d * 4 * H + (i / HH) * H + p * HH + (i % HH)] : 0.f;
+
+  int bdoc[LP_GROUPS], len[LP_GROUPS];
+  int maxlen = 0;
+#pragma unroll
+  for (int g = 0; g < LP_GROUPS; ++g) {
+    bdoc[g] = (gx * LP_GROUPS + g) * LP_DOCS + doc;
+    len[g] = (bdoc[g] < B) ? (lengths ? min(lengths[bdoc[g]], L) : L) : 0;
+    maxlen = max(maxlen, len[g]);
+  }
+#pragma unroll
+  for (int off = 1; off < 16; off <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
+
+  // exchange areas: xch[pair][group][half][parity][1024 granules]; granule index = doc*64 + (unit within half)/2
+  auto xarea = [&](int g, int half, int par) { return xch + ((((size_t)pair * LP_GROUPS + g) * 2 + half) * 2 + par) * 1024; };
+
+  float c[LP_GROUPS][4];
+  uint2 hq[LP_GROUPS];
+  uint2 xb[LP_GROUPS][4];                                // x rows of the next step of each group (refilled right after use)
+#pragma unroll
+  for (int g = 0; g < LP_GROUPS; ++g) {
+    hq[g] = make_uint2(0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[g][r] = 0.f;
+  }
+  for (int i = tid; i < LP_GROUPS * 2 * LP_DOCS * HROW / 16; i += NT) reinterpret_cast<uint4*>(hbuf)[i] = make_uint4(0, 0, 0, 0);
+
+  auto xrow = [&](int g, int s) -> long {
+    if (s >= len[g]) return -1;
+    const int t = (d == 0) ? s : (len[g] - 1 - s);
+    return (long)bdoc[g] * L + t;
+  };
+  auto load_x = [&](int g, int s) {
+    const long row = xrow(g, s);
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt)
+      xb[g][gt] = (row >= 0) ? *reinterpret_cast<const uint2*>(xproj + (size_t)row * ldx + (size_t)d * 4 * H + gt * H + u) : make_uint2(0, 0);
+  };
+  bool dead = x_nowait;
+  // partner's half of h for (group g, after step s) -> LDS hbuf[g][(s+1)&1].  The first poll is ISSUED early (before the
+  // caller's stores: vmcnt retires in order, a load queued behind stores waits for their write acks) and only checked
+  // here; bounded re-polling if a tag is not there yet.
+  u64 v[GPT];
+  auto fetch_issue = [&](int g, int s) {
+    const u64* src = xarea(g, 1 - p, (s + 1) & 1);
+#pragma unroll
+    for (int k = 0; k < GPT; ++k) v[k] = __hip_atomic_load(src + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto fetch = [&](int g, int s) {
+    const u64* src = xarea(g, 1 - p, (s + 1) & 1);
+    const unsigned epoch = (unsigned)(s + 1);
+    unsigned spins = 0;
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int k = 0; k < GPT; ++k) ok &= ((unsigned)(v[k] >> 32) == epoch);
+      if (__all(ok) || dead) break;
+      if (++spins > LP_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(status, 1u); break; }
+      __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+      for (int k = 0; k < GPT; ++k) v[k] = __hip_atomic_load(src + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    char* dst = hbuf + ((g * 2 + ((s + 1) & 1)) * LP_DOCS) * HROW;
+#pragma unroll
+    for (int k = 0; k < GPT; ++k) {
+      const int gi = tid + NT * k;                       // granule: doc = gi / 64, unit pair = gi % 64
+      *reinterpret_cast<unsigned*>(dst + (gi >> 6) * HROW + ((1 - p) * HH + (gi & 63) * 2) * 2) = (unsigned)v[k];
+    }
+  };
+
+#pragma unroll
+  for (int g = 0; g < LP_GROUPS; ++g) load_x(g, 0);
+  __syncthreads();
+
+  // one time step of both groups; PAR = s & 1 is a compile-time constant so the x buffers are statically indexed
+  auto step = [&](auto parc, int s) {
+    constexpr int PAR = decltype(parc)::value;
+#pragma unroll
+    for (int g = 0; g < LP_GROUPS; ++g) {
+      const char* hcur = hbuf + ((g * 2 + PAR) * LP_DOCS) * HROW;
+      char* hnext = hbuf + ((g * 2 + (PAR ^ 1)) * LP_DOCS) * HROW;
+      bf16x8 hf[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) hf[ks] = *reinterpret_cast<const bf16x8*>(hcur + doc * HROW + (ks * 32 + 8 * g4) * 2);
+      f32x4 acc[4];
+#pragma unroll
+      for (int gt = 0; gt < 4; ++gt) acc[gt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (!x_nomfma) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+          for (int gt = 0; gt < 3; ++gt) acc[gt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[gt][ks], hf[ks], acc[gt], 0, 0, 0);
+          acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wl + ks * 1024 + lane * 16), hf[ks], acc[3], 0, 0, 0);
+        }
+      }
+
+      const int og = (g + 1) % LP_GROUPS;
+      const int os = (g == LP_GROUPS - 1) ? s : s - 1;   // group og last finished step os
+      const bool active = s < len[g];
+      const long row = xrow(g, s);
+      float gi[4], gf[4], gg[4], go[4];
+      if (active) {
+        float xi[4], xf[4], xg[4], xo[4], hn[4];
+        upk4(xb[g][0], xi); upk4(xb[g][1], xf); upk4(xb[g][2], xg); upk4(xb[g][3], xo);
+        const float4 bi = *reinterpret_cast<const float4*>(blds + ul), bf = *reinterpret_cast<const float4*>(blds + HH + ul);
+        const float4 bg = *reinterpret_cast<const float4*>(blds + 2 * HH + ul), bo = *reinterpret_cast<const float4*>(blds + 3 * HH + ul);
+        const float bia[4][4] = {{bi.x, bi.y, bi.z, bi.w}, {bf.x, bf.y, bf.z, bf.w}, {bg.x, bg.y, bg.z, bg.w}, {bo.x, bo.y, bo.z, bo.w}};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (x_nomath) {
+            gi[r] = (xi[r] + bia[0][r]) + acc[0][r]; gf[r] = (xf[r] + bia[1][r]) + acc[1][r];
+            gg[r] = (xg[r] + bia[2][r]) + acc[2][r]; go[r] = (xo[r] + bia[3][r]) + acc[3][r];
+            c[g][r] = gf[r] * c[g][r] + gi[r] * gg[r];
+            hn[r] = go[r] * c[g][r];
+          } else {
+            gi[r] = fsig2((xi[r] + bia[0][r]) + acc[0][r]);
+            gf[r] = fsig2((xf[r] + bia[1][r]) + acc[1][r]);
+            gg[r] = ftanh2((xg[r] + bia[2][r]) + acc[2][r]);
+            go[r] = fsig2((xo[r] + bia[3][r]) + acc[3][r]);
+            c[g][r] = gf[r] * c[g][r] + gi[r] * gg[r];
+            hn[r] = go[r] * ftanh2(c[g][r]);
+          }
+        }
+        hq[g] = pk4(hn);
+      }
+      // 1) post the own half of the new h first (shortest exchange path): LDS for this workgroup, tagged granules for
+      //    the partner (inactive documents carry h)
+      *reinterpret_cast<uint2*>(hnext + doc * HROW + u * 2) = hq[g];
+      if (!x_nopost) {
+        u64* mine = xarea(g, p, PAR ^ 1);
+        const u64 tag = (u64)(unsigned)(s + 1) << 32;
+        __hip_atomic_store(mine + doc * 64 + (ul >> 1), tag | hq[g].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + doc * 64 + (ul >> 1) + 1, tag | hq[g].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // 2) first poll of the OTHER group's partner half: posted about one phase ago, so it normally succeeds; it is
+      //    issued before the bulk stores below (vmcnt retires in order)
+      if (os >= 0 && !x_nofetch) fetch_issue(og, os);
+      // 3) saved state for the backward pass
+      if (active && !x_nostore) {
+        bf16_t* gp = gates + (size_t)row * ldx + (size_t)d * 4 * H + u;
+        *reinterpret_cast<uint2*>(gp) = pk4(gi);
+        *reinterpret_cast<uint2*>(gp + H) = pk4(gf);
+        *reinterpret_cast<uint2*>(gp + 2 * H) = pk4(gg);
+        *reinterpret_cast<uint2*>(gp + 3 * H) = pk4(go);
+        *reinterpret_cast<float4*>(cells + (size_t)row * ldo + (size_t)d * H + u) = make_float4(c[g][0], c[g][1], c[g][2], c[g][3]);
+        *reinterpret_cast<uint2*>(out + (size_t)row * ldo + (size_t)d * H + u) = hq[g];
+      }
+      if (!x_nox) load_x(g, s + 1);                        // needed one step (two phases) from here
+      // the OTHER group's partner half was posted one compute phase ago: finish its fetch, then both halves are in LDS
+      if (os >= 0 && !x_nofetch) fetch(og, os);
+      if (!x_nobar) __syncthreads();
+    }
+  };
+  for (int s = 0; s < maxlen; s += 2) {
+    step(std::integral_constant<int, 0>{}, s);
+    if (s + 1 < maxlen) step(std::integral_constant<int, 1>{}, s + 1);
+  }
+  // rows >= len are exactly zero
+#pragma unroll
+  for (int g = 0; g < LP_GROUPS; ++g)
+    if (bdoc[g] < B)
+      for (int t = len[g] + g4; t < L; t += 4)
+        for (int e = 0; e < 16; e += 4) *reinterpret_cast<uint2*>(out + ((size_t)bdoc[g] * L + t) * ldo + (size_t)d * H + p * HH + w * 16 + e) = make_uint2(0, 0);
+}
+
+// ---- host side ---------------------------------------------------------------------------------------
+static int g_pair_mode = -1;   // MTS_LSTM_PAIR=0 disables
+
+bool mts_lstm_pair_supported(int dtype, int H) {
+  if (g_pair_mode < 0) { const char* e = getenv("MTS_LSTM_PAIR"); g_pair_mode = (e && e[0] == '0') ? 0 : 1; }
+  return g_pair_mode && dtype == MTS_BF16 && H == 256;
+}
+
+// workspace: packed weights (bf16) | exchange granules | status word
+static size_t pair_wbytes(int H, int ndir) { return align_up((size_t)ndir * 4 * H * H * 2, 256); }
+static size_t pair_xbytes(int B, int ndir) { return align_up((size_t)ceil_div(B, LP_DOCS * LP_GROUPS) * ndir * LP_GROUPS * 2 * 2 * 1024 * sizeof(u64), 256); }
+size_t mts_lstm_pair_workspace(int B, int H, int ndir) { return pair_wbytes(H, ndir) + pair_xbytes(B, ndir) + 256; }
+
+int mts_lstm_pair_fwd(hipStream_t st, int B, int L, int H, int ndir, const void* xproj, const float* w_hh, const float* b_hh,
+                      const int32_t* lengths, void* out, void* gates, float* cells, void* ws) {
+  constexpr int KS = 8;
+  bf16_t* wpk = (bf16_t*)ws;
+  u64* xch = (u64*)((char*)ws + pair_wbytes(H, ndir));
+  unsigned* status = (unsigned*)((char*)xch + pair_xbytes(B, ndir));
+  const size_t total = (size_t)ndir * 2 * KS * 4 * KS * 64;
+  hipLaunchKernelGGL(lstm_pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w_hh, wpk, H, ndir);
+  if (hipMemsetAsync(xch, 0, pair_xbytes(B, ndir) + 256, st) != hipSuccess) { mts_set_error("lstm_pair: memset failed"); return MTS_ERR_LAUNCH; }
+  const size_t lds = (size_t)LP_GROUPS * 2 * LP_DOCS * (H + 8) * 2 + (size_t)4 * (H / 2) * sizeof(float) + (size_t)KS * KS * 1024;
+  auto k = lstm_fwd_pair_kernel<KS>;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      mts_set_error("lstm_pair_fwd: cannot reserve %zu bytes of LDS", lds);
+      return MTS_ERR_LAUNCH;
+    }
+    attr = true;
+  }
+  static int xflags = -1;
+  if (xflags < 0) { const char* e = getenv("MTS_LSTM_EXP"); xflags = e ? atoi(e) : 0; }
+  const int npairs = ceil_div(B, LP_DOCS * LP_GROUPS) * ndir;
+  hipLaunchKernelGGL(k, dim3(16 * ceil_div(npairs, 8)), dim3(KS * 64), lds, st, B, L, ndir, npairs, (const bf16_t*)xproj, (const bf16_t*)wpk, b_hh,
+                     lengths, (bf16_t*)out, (bf16_t*)gates, cells, xch, status, xflags);
+  MTS_LAUNCH_CHECK("mts_lstm_fwd(pair)");
+  return MTS_OK;
+}
+
+// =====================================================================================================
+// backward, CU-pair form.  Half p owns the gate columns of its own 128 units (da_own, 16 x 512 per group) and keeps
+// W_hh[own columns][all 256 units] resident; per step it computes the partial  dh[:, all units] = da_own . W_own,
+// keeps the 128 columns of its own units (LDS, fp32) and sends the other 128 to the partner as bf16 granules.
+// Elementwise gate-gradient work is spread over all 512 threads (thread = document x 4 own units).
+// =====================================================================================================
+// packed: wpkT[d][p][w][t][ks][lane] = 8 bf16: A fragment row = unit j = w*32 + t*16 + (lane&15), k = own column index
+// kk = ks*32 + 8*(lane>>4) .. +7, i.e. W_hh[gate*H + p*H/2 + kk%128][j] with gate = kk/128
+__global__ void lstm_pack_weights_T_kernel(const float* __restrict__ w_hh, bf16_t* __restrict__ wpk, int H, int ndir) {
+  const int HH = H / 2, KT = 4 * HH / 32, NW = H / 32;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // over d, p, w, t, ks, lane
+  const size_t total = (size_t)ndir * 2 * NW * 2 * KT * 64;
+  if (idx >= total) return;
+  const int lane = idx % 64;
+  size_t r = idx / 64;
+  const int ks = r % KT; r /= KT;
+  const int t = r % 2; r /= 2;
+  const int w = r % NW; r /= NW;
+  const int p = r % 2; r /= 2;
+  const int d = (int)r;
+  const int j = w * 32 + t * 16 + (lane & 15);
+  bf16_t* dst = wpk + idx * 8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int kk = ks * 32 + 8 * (lane >> 4) + e;
+    const int n = (kk / HH) * H + p * HH + (kk % HH);
+    dst[e] = (bf16_t)w_hh[((size_t)d * 4 * H + n) * H + j];
+  }
+}
+
+struct PairBwdIn { uint2 gi, gf, gg, go, dov; float4 ct, cp; };
+
+template <int KS>
+__global__ __launch_bounds__(KS * 64, 2) void lstm_bwd_pair_kernel(int B, int L, int ndir, int npairs, const bf16_t* __restrict__ wpkT,
+                                                                   const int32_t* __restrict__ lengths, const bf16_t* __restrict__ gates,
+                                                                   const float* __restrict__ cells, const bf16_t* __restrict__ dout,
+                                                                   bf16_t* __restrict__ dxproj, u64* __restrict__ xch, unsigned* __restrict__ status) {
+  constexpr int H = KS * 32, HH = H / 2, NT = KS * 64, GPT = 1024 / NT;
+  constexpr int KT = 4 * HH / 32;                        // k-steps over the 512 own gate columns
+  constexpr int RK = KT + KT / 2;                        // fragments kept in registers: tile 0 all, tile 1 first half
+  constexpr int DAROW = (4 * HH + 8) * 2;                // bytes per da row
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* dabuf = smem;                                                       // [group][16][DAROW] bf16
+  float* dhl = reinterpret_cast<float*>(dabuf + LP_GROUPS * LP_DOCS * DAROW);   // [group][16][HH] own partial (fp32)
+  unsigned* dhp = reinterpret_cast<unsigned*>(dhl + LP_GROUPS * LP_DOCS * HH);   // [group][16][HH/2] partner partial (2 x bf16)
+  char* wlds = reinterpret_cast<char*>(dhp + LP_GROUPS * LP_DOCS * HH / 2);     // [wave][KT/2][1024]
+  const int chunk = blockIdx.x / 16, within = blockIdx.x % 16;
+  const int p = within / 8, pair = chunk * 8 + within % 8;
+  if (pair >= npairs) return;
+  const int gx = pair / ndir, d = pair % ndir;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mdoc = lane & 15, g4 = lane >> 4;            // MFMA lane roles
+  const int edoc = tid & 15, eq = tid >> 4;              // elementwise roles: document, unit quad (4 own units)
+  const int ul = eq * 4, u = p * HH + ul;
+  const int ldx = ndir * 4 * H, ldo = ndir * H;
+
+  bf16x8 wreg[RK];
+  char* wl = wlds + (size_t)w * (KT / 2) * 1024;
+  {
+    const bf16_t* base = wpkT + ((((size_t)d * 2 + p) * KS + w) * 2 * KT * 64) * 8;
+#pragma unroll
+    for (int f = 0; f < RK; ++f) wreg[f] = *reinterpret_cast<const bf16x8*>(base + ((size_t)f * 64 + lane) * 8);
+#pragma unroll
+    for (int f = 0; f < KT / 2; ++f)
+      *reinterpret_cast<bf16x8*>(wl + f * 1024 + lane * 16) = *reinterpret_cast<const bf16x8*>(base + ((size_t)(RK + f) * 64 + lane) * 8);
+  }
+
+  int bdoc[LP_GROUPS], len[LP_GROUPS];
+  int maxlen = 0;
+#pragma unroll
+  for (int g = 0; g < LP_GROUPS; ++g) {
+    bdoc[g] = (gx * LP_GROUPS + g) * LP_DOCS + edoc;
+    len[g] = (bdoc[g] < B) ? (lengths ? min(lengths[bdoc[g]], L) : L) : 0;
+    maxlen = max(maxlen, len[g]);
+  }
+#pragma unroll
+  for (int off = 1; off < 16; off <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
+  // (tid & 15 == lane & 15, so the xor-reduction over 16 lanes covers the 16 documents for both lane roles)
+
+  auto xarea = [&](int g, int half, int par) { return xch + ((((size_t)pair * LP_GROUPS + g) * 2 + half) * 2 + par) * 1024; };
+  for (int i = tid; i < (int)((LP_GROUPS * LP_DOCS * (DAROW + HH * 4 + HH * 2)) / 4); i += NT) reinterpret_cast<unsigned*>(smem)[i] = 0u;
+
+  auto load_in = [&](int g, int s, PairBwdIn& in) {
+    const bool act = (s >= 0) && (s < len[g]);
+    const int t = (d == 0) ? s : (len[g] - 1 - s);
+    const int tp = (d == 0) ? t - 1 : t + 1;
+    const size_t row = (size_t)bdoc[g] * L + (act ? t : 0);
+    const size_t prow = (size_t)bdoc[g] * L + ((act && s > 0) ? tp : 0);
+    const uint2 z2 = make_uint2(0, 0);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bf16_t* gp = gates + row * ldx + (size_t)d * 4 * H + u;
+    in.gi = act ? *reinterpret_cast<const uint2*>(gp) : z2;
+    in.gf = act ? *reinterpret_cast<const uint2*>(gp + H) : z2;
+    in.gg = act ? *reinterpret_cast<const uint2*>(gp + 2 * H) : z2;
+    in.go = act ? *reinterpret_cast<const uint2*>(gp + 3 * H) : z2;
+    in.dov = act ? *reinterpret_cast<const uint2*>(dout + row * ldo + (size_t)d * H + u) : z2;
+    in.ct = act ? *reinterpret_cast<const float4*>(cells + row * ldo + (size_t)d * H + u) : z4;
+    in.cp = (act && s > 0) ? *reinterpret_cast<const float4*>(cells + prow * ldo + (size_t)d * H + u) : z4;
+  };
+  bool dead = false;
+  u64 v[GPT];
+  // partner's partial dh for my units, produced in its MFMA of (group g, step s); tag = maxlen - s (>= 1)
+  auto fetch_issue = [&](int g, int s) {
+    const u64* src = xarea(g, 1 - p, s & 1);
+#pragma unroll
+    for (int k = 0; k < GPT; ++k) v[k] = __hip_atomic_load(src + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto fetch = [&](int g, int s) {
+    const u64* src = xarea(g, 1 - p, s & 1);
+    const unsigned epoch = (unsigned)(maxlen - s);
+    unsigned spins = 0;
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int k = 0; k < GPT; ++k) ok &= ((unsigned)(v[k] >> 32) == epoch);
+      if (__all(ok) || dead) break;
+      if (++spins > LP_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(status, 2u); break; }
+      __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+      for (int k = 0; k < GPT; ++k) v[k] = __hip_atomic_load(src + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int k = 0; k < GPT; ++k) dhp[(size_t)g * LP_DOCS * (HH / 2) + tid + NT * k] = (unsigned)v[k];   // [doc][pair] = granule order
+  };
+
+  float dc[LP_GROUPS][4];
+  PairBwdIn in[LP_GROUPS];
+#pragma unroll
+  for (int g = 0; g < LP_GROUPS; ++g) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dc[g][r] = 0.f;
+    load_in(g, maxlen - 1, in[g]);
+  }
+  __syncthreads();
+
+  for (int s = maxlen - 1; s >= 0; --s) {
+#pragma unroll
+    for (int g = 0; g < LP_GROUPS; ++g) {
+      // ---- elementwise: dh = own partial + partner partial (+ dOut) -> gate pre-activation gradients -------------
+      char* da = dabuf + g * LP_DOCS * DAROW;
+      const bool active = s < len[g];
+      float ai[4] = {0.f, 0.f, 0.f, 0.f}, af[4] = {0.f, 0.f, 0.f, 0.f}, ag[4] = {0.f, 0.f, 0.f, 0.f}, ao[4] = {0.f, 0.f, 0.f, 0.f};
+      if (active) {
+        const float4 own = *reinterpret_cast<const float4*>(dhl + ((size_t)g * LP_DOCS + edoc) * HH + ul);
+        const uint2 oth = *reinterpret_cast<const uint2*>(dhp + ((size_t)g * LP_DOCS + edoc) * (HH / 2) + (ul >> 1));
+        const float dhv[4] = {own.x + bf16_lo(oth.x), own.y + bf16_hi(oth.x), own.z + bf16_lo(oth.y), own.w + bf16_hi(oth.y)};
+        float gi[4], gf[4], gg[4], go[4], dov[4];
+        upk4(in[g].gi, gi); upk4(in[g].gf, gf); upk4(in[g].gg, gg); upk4(in[g].go, go); upk4(in[g].dov, dov);
+        const float ct[4] = {in[g].ct.x, in[g].ct.y, in[g].ct.z, in[g].ct.w};
+        const float cp[4] = {in[g].cp.x, in[g].cp.y, in[g].cp.z, in[g].cp.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float tc = ftanh2(ct[r]);
+          const float dht = dov[r] + dhv[r];
+          const float dct = dc[g][r] + dht * go[r] * (1.f - tc * tc);
+          ai[r] = dct * gg[r] * gi[r] * (1.f - gi[r]);
+          af[r] = dct * cp[r] * gf[r] * (1.f - gf[r]);
+          ag[r] = dct * gi[r] * (1.f - gg[r] * gg[r]);
+          ao[r] = dht * tc * go[r] * (1.f - go[r]);
+          dc[g][r] = dct * gf[r];
+        }
+      }
+      const uint2 qi = pk4(ai), qf = pk4(af), qg = pk4(ag), qo = pk4(ao);
+      char* dr = da + edoc * DAROW + ul * 2;
+      *reinterpret_cast<uint2*>(dr) = qi;
+      *reinterpret_cast<uint2*>(dr + HH * 2) = qf;
+      *reinterpret_cast<uint2*>(dr + 2 * HH * 2) = qg;
+      *reinterpret_cast<uint2*>(dr + 3 * HH * 2) = qo;
+      // poll for the other group's partner partial (posted about a phase ago) goes out before this phase's stores
+      const int og = (g + 1) % LP_GROUPS;
+      const int os = (g == LP_GROUPS - 1) ? s : s + 1;   // the step of group og whose partial is needed next
+      const bool need = (g == LP_GROUPS - 1) ? (s - 1 >= 0) : (s + 1 <= maxlen - 1);
+      // group og's next elementwise is (og, os - 1) for g = last, or (og, s) for g = 0; it needs the partial of step os
+      if (need) fetch_issue(og, os);
+      if (active) {
+        const int t = (d == 0) ? s : (len[g] - 1 - s);
+        bf16_t* dx = dxproj + ((size_t)bdoc[g] * L + t) * ldx + (size_t)d * 4 * H + u;
+        *reinterpret_cast<uint2*>(dx) = qi;
+        *reinterpret_cast<uint2*>(dx + H) = qf;
+        *reinterpret_cast<uint2*>(dx + 2 * H) = qg;
+        *reinterpret_cast<uint2*>(dx + 3 * H) = qo;
+      }
+      load_in(g, s - 1, in[g]);
+      __syncthreads();
+      // ---- partial dh for all 256 units from the own gate columns -------------------------------------------------
+      f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int ks = 0; ks < KT; ++ks) {
+        const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(da + mdoc * DAROW + (ks * 32 + 8 * g4) * 2);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[ks], bfr, acc[0], 0, 0, 0);
+        const bf16x8 w1 = (ks < KT / 2) ? wreg[KT + ks] : *reinterpret_cast<const bf16x8*>(wl + (ks - KT / 2) * 1024 + lane * 16);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, bfr, acc[1], 0, 0, 0);
+      }
+      const bool mine_half = (w / (KS / 2)) == p;        // this wave's 32 units belong to my half
+      const unsigned tag = (unsigned)(maxlen - s);
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const int ulw = (w % (KS / 2)) * 32 + t2 * 16 + 4 * g4;       // unit within its half
+        if (mine_half) {
+          *reinterpret_cast<float4*>(dhl + ((size_t)g * LP_DOCS + mdoc) * HH + ulw) = make_float4(acc[t2][0], acc[t2][1], acc[t2][2], acc[t2][3]);
+        } else {
+          u64* dst = xarea(g, p, s & 1) + mdoc * 64 + (ulw >> 1);
+          const float vv[4] = {acc[t2][0], acc[t2][1], acc[t2][2], acc[t2][3]};
+          const uint2 pk = pk4(vv);
+          __hip_atomic_store(dst, ((u64)tag << 32) | pk.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(dst + 1, ((u64)tag << 32) | pk.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (need) fetch(og, os);
+      __syncthreads();
+    }
+  }
+  // rows >= len: zero gradients (the GEMMs that follow read every row)
+#pragma unroll
+  for (int g = 0; g < LP_GROUPS; ++g)
+    if (bdoc[g] < B)
+      for (int t = len[g]; t < L; ++t)
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt) *reinterpret_cast<uint2*>(dxproj + ((size_t)bdoc[g] * L + t) * ldx + (size_t)d * 4 * H + gt * H + u) = make_uint2(0, 0);
+}
+
+// hprev[b, t] = out[b, t_prev] (zero at a document's first processed position and on padded rows), per direction
+template <typename T>
+__global__ void lstm_hprev_kernel(int B, int L, int H, int ndir, const int32_t* __restrict__ lengths, const T* __restrict__ out, T* __restrict__ hprev) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // over rows x ndir x H/4
+  const int per_row = ndir * H / 4;
+  if (idx >= (size_t)B * L * per_row) return;
+  const size_t row = idx / per_row;
+  const int c = (int)(idx % per_row) * 4, d = c / H;
+  const int b = (int)(row / L), t = (int)(row % L);
+  const int len = lengths ? min(lengths[b], L) : L;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  const int tp = (d == 0) ? t - 1 : t + 1;
+  if (t < len && tp >= 0 && tp < len) load4<T>(out + ((size_t)b * L + tp) * ndir * H + c, v);
+  store4<T>(hprev + row * ndir * H + c, v);
+}
+
+int mts_lstm_pair_bwd(hipStream_t st, int B, int L, int H, int ndir, const float* w_hh, const int32_t* lengths, const void* out, const void* gates,
+                      const float* cells, const void* dout, void* dxproj, void* hprev, void* ws) {
+  constexpr int KS = 8;
+  bf16_t* wpk = (bf16_t*)ws;
+  u64* xch = (u64*)((char*)ws + pair_wbytes(H, ndir));
+  unsigned* status = (unsigned*)((char*)xch + pair_xbytes(B, ndir));
+  const int HH = H / 2, KT = 4 * HH / 32;
+  const size_t total = (size_t)ndir * 2 * KS * 2 * KT * 64;
+  hipLaunchKernelGGL(lstm_pack_weights_T_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w_hh, wpk, H, ndir);
+  if (hipMemsetAsync(xch, 0, pair_xbytes(B, ndir) + 256, st) != hipSuccess) { mts_set_error("lstm_pair: memset failed"); return MTS_ERR_LAUNCH; }
+  const size_t rows4 = (size_t)B * L * ndir * H / 4;
+  hipLaunchKernelGGL(lstm_hprev_kernel<bf16_t>, dim3((unsigned)((rows4 + 255) / 256)), dim3(256), 0, st, B, L, H, ndir, lengths, (const bf16_t*)out,
+                     (bf16_t*)hprev);
+  const size_t lds = (size_t)LP_GROUPS * LP_DOCS * ((4 * HH + 8) * 2 + HH * 4 + HH * 2) + (size_t)KS * (KT / 2) * 1024;
+  auto k = lstm_bwd_pair_kernel<KS>;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      mts_set_error("lstm_pair_bwd: cannot reserve %zu bytes of LDS", lds);
+      return MTS_ERR_LAUNCH;
+    }
+    attr = true;
+  }
+  const int npairs = ceil_div(B, LP_DOCS * LP_GROUPS) * ndir;
+  hipLaunchKernelGGL(k, dim3(16 * ceil_div(npairs, 8)), dim3(KS * 64), lds, st, B, L, ndir, npairs, (const bf16_t*)wpk, lengths, (const bf16_t*)gates,
+                     cells, (const bf16_t*)dout, (bf16_t*)dxproj, xch, status);
+  MTS_LAUNCH_CHECK("mts_lstm_bwd(pair)");
+  return MTS_OK;
+}
