@@ -106,6 +106,13 @@ class _TaggerBase(FlatModule):
             self._wcopy_version = ver
         return self._wcopy
 
+    _grad_hook = None
+
+    def _grads_ready(self, a, b):
+        """Flat-gradient span [a, b) is final for this step (hook installed by trainer.NativeTrainer for RCCL overlap)."""
+        if self._grad_hook is not None and b > a:
+            self._grad_hook(a, b)
+
     def mark_weights_synced(self):
         """The fused optimizer wrote the bf16 mirror itself: skip the next cast."""
         self._wcopy_version = self._flat._version
@@ -348,6 +355,11 @@ class Transformer_segmenter(_TaggerBase):
                               dxsum=G(lp + 'attention.output.dense.bias'))
             # attention output projection: s1 = ctx Wo^T + bo + hin
             ops.linear_wgrad(ds1, S['ctx'], G(lp + 'attention.output.dense.weight'))
+            # everything of this layer behind the q/k/v block (and the head, for the last layer) is final: let a
+            # data-parallel trainer start reducing it while attention backward and the QKV GEMMs still run
+            o0, _ = lay.entries[lp + 'attention.output.dense.weight']
+            o1 = lay.entries[f'model.model.encoder.layer.{li + 1}.attention.self.query.weight'][0] if li + 1 < nl else g.numel()
+            self._grads_ready(o0, o1)
             dctx = ws.get('dctx', N, D, dt, dev)
             ops.linear_dgrad(ds1, self._w(wf, lp + 'attention.output.dense.weight'), dctx)
             dqkv = ws.get('dqkv', N, 3 * D, dt, dev)
@@ -358,6 +370,7 @@ class Transformer_segmenter(_TaggerBase):
             ops.colsum(dqkv, g[off:off + n])
             off, n = lay.span(a_ + 'query.weight', a_ + 'value.weight')
             ops.linear_wgrad(dqkv, S['hin'], g[off:off + n].view(3 * D, D))
+            self._grads_ready(off, lay.entries[lp + 'attention.output.dense.weight'][0])    # q/k/v weights + biases
             dhin = ws.get(f'dhin{li & 1}', N, D, dt, dev)
             ops.linear_dgrad(dqkv, self._wspan(wf, a_ + 'query.weight', a_ + 'value.weight', 3 * D, D), dhin, residual=ds1)
             dh = dhin
@@ -369,6 +382,11 @@ class Transformer_segmenter(_TaggerBase):
                           G(e + 'LayerNorm.weight'), G(e + 'LayerNorm.bias'), dxsum=G(e + 'token_type_embeddings.weight')[0])
         G(e + 'position_embeddings.weight').zero_()
         ops.embed_bwd(dpre, B, Lq, G(e + 'position_embeddings.weight'), 2)
+        # embeddings: only the position rows a batch of this length can touch, then type row + LayerNorm
+        D_ = self.embedding_dim
+        p0 = lay.entries[e + 'position_embeddings.weight'][0]
+        self._grads_ready(p0 + 2 * D_, p0 + (Lq + 2) * D_)
+        self._grads_ready(lay.entries[e + 'token_type_embeddings.weight'][0], lay.entries['model.model.encoder.layer.0.attention.self.query.weight'][0])
 
     # ---- public API ------------------------------------------------------------------------------------
     def loss_and_grad(self, xs, lengths, tags, want_grad=True):

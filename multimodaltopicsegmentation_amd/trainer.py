@@ -64,6 +64,7 @@ class NativeTrainer:
         return [(0, n)]
 
     def allreduce_grads(self):
+        """Blocking exchange of every span (models without gradient-ready hooks, e.g. the recurrent taggers)."""
         if self.world == 1:
             return
         g = self.model.grad_flat()
@@ -71,16 +72,31 @@ class NativeTrainer:
             if b > a:
                 dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, group=self.pg)
 
+    def _on_grads_ready(self, a, b):
+        """Called from inside the backward as soon as flat-gradient span [a, b) is final: the all-reduce is enqueued
+        asynchronously (RCCL runs it on its own stream behind the kernels issued so far), so it overlaps the rest of
+        the backward; few large messages because ring collectives over xGMI are per-link-bound."""
+        g = self.model.grad_flat()
+        self._pending.append(dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
     def step(self, batch):
         """One optimizer step on this rank's shard; returns the local loss (0-d tensor)."""
         m = self.model
         x, lengths, tags = batch['src_tokens'], batch['src_lengths'], batch['tgt_tokens']
         self._last_L = x.shape[1]
+        overlapped = self.world > 1 and hasattr(m, '_grads_ready') and type(m).__name__ == 'Transformer_segmenter'
+        self._pending = []
+        m._grad_hook = self._on_grads_ready if overlapped else None
         if batch.get('src_tokens2') is not None and hasattr(m, '_rnn2'):
             loss, _ = m.loss_and_grad(x, batch['src_tokens2'], lengths, tags, True)
         else:
             loss, _ = m.loss_and_grad(x, lengths, tags, True)
-        self.allreduce_grads()
+        if overlapped:
+            for h in self._pending:
+                h.wait()                      # stream-level wait: the optimizer kernel is ordered behind the collectives
+            self._pending = []
+        else:
+            self.allreduce_grads()
         self.apply_optimizer()
         return loss
 

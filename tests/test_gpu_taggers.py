@@ -274,3 +274,30 @@ def test_state_dict_roundtrip_and_dead_keys():
     s1, _ = a.model(x, lens)
     s2, _ = b.model(x, lens)
     assert torch.equal(s1, s2)
+
+
+# ------------------------------------------------------------------------------------------------ data-parallel overlap (row e)
+def test_gradient_ready_spans_are_final_disjoint_and_cover_every_gradient():
+    """trainer.NativeTrainer starts the RCCL all-reduce of a flat-gradient span from inside the backward: every span
+    handed to the hook must already hold its final value, spans must not overlap, and nothing outside them may be non-zero."""
+    from multimodaltopicsegmentation_amd.taggers import Transformer_segmenter
+    B, L, D = 3, 24, 64
+    m = Transformer_segmenter(2, D, 32, num_layers=3, nheads=4, loss_fn='FocalLoss', window_size=4, compute_dtype='fp32',
+                              max_position_embedding=64, seed=11).to(DEV)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, L, D, generator=g).to(DEV)
+    y = (torch.rand(B, L, generator=g) < 0.3).float().to(DEV)
+    lengths = torch.tensor([24, 17, 9])
+    seen = []
+    m._grad_hook = lambda a, b: seen.append((a, b, m.grad_flat()[a:b].clone()))
+    m.loss_and_grad(x, lengths, y, True)
+    m._grad_hook = None
+    final = m.grad_flat().clone()
+    covered = torch.zeros(final.numel(), dtype=torch.int32)
+    for a, b, snap in seen:
+        assert torch.equal(snap, final[a:b]), (a, b)
+        covered[a:b] += 1
+    assert int(covered.max()) == 1
+    assert torch.count_nonzero(final.cpu()[covered == 0]) == 0
+    assert len(seen) == 2 * 3 + 2                         # per layer: tail block + q/k/v block; embeddings: positions + rest
+    assert torch.count_nonzero(final) > 0.9 * int(covered.sum())
