@@ -17,21 +17,10 @@
 //
 // Semantics (oracle/restatement.py::band_attention; modeling_longformer.py:482-640): key j = i - radius + c
 // takes part iff 0 <= j < len_b; a query i >= len_b yields a zero row.
-#include "common.h"
+#include "band_common.h"
 
 #define TQ 32
 #define KV_ROWS (TQ + 31)
-
-struct BandArgs {
-  const void* qkv; const int32_t* lengths; void* ctx; float* probs;
-  const void* dctx; void* dqkv; float* dscores;
-  int B, L, D, heads, hd, radius, slots;
-  int rs;      // LDS row stride (bytes) of staged q/k/v rows
-  int ps;      // LDS row stride (floats) of the probability tile
-  float q_scale;
-};
-
-__host__ __device__ inline int band_slots(int radius) { return ((2 * radius + 1 + 31) / 32) * 32; }
 
 // ---- staging: rows [first, first+nrows) of one head's slice of a [B*L, ld] matrix into LDS; rows outside [0,L) -> 0
 template <typename T>
@@ -108,16 +97,6 @@ __device__ __forceinline__ float oct_max(float v) {   // reduce over the 8 lanes
 __device__ __forceinline__ float oct_sum(float v) {
   v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
   return v;
-}
-
-// decode the XCD-remapped linear block id into (tile, head, doc): consecutive tiles of one (doc, head) stay on one XCD
-__device__ __forceinline__ void decode_block(int ntiles, int heads, int nblocks, int& tile, int& h, int& b) {
-  int bid = blockIdx.x;
-  const int q = nblocks >> 3, rr = nblocks & 7, xcd = bid & 7, idx = bid >> 3;
-  bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
-  tile = bid % ntiles;
-  h = (bid / ntiles) % heads;
-  b = bid / (ntiles * heads);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -343,6 +322,9 @@ __global__ __launch_bounds__(256) void band_bwd_kv_kernel(const BandArgs a) {
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+static int g_band_mfma = 1;           // mts_set_option("band_mfma", 0) forces the generic kernels (A/B testing)
+void mts_band_set_mfma(int on) { g_band_mfma = on; }
+
 extern "C" int mts_band_slots(int radius) { return band_slots(radius); }
 
 static int band_row_stride(int hd, int esize) {
@@ -395,6 +377,10 @@ extern "C" int mts_band_attn_fwd(void* stream, int dtype, int B, int L, int D, i
   if (rc) return rc;
   MTS_CHECK_ARG(qkv && ctx && probs, "mts_band_attn_fwd: null pointer");
   a.qkv = qkv; a.lengths = lengths; a.ctx = ctx; a.probs = probs;
+  if (dtype == MTS_BF16 && g_band_mfma) {
+    rc = mts_band_mfma_fwd(a, (hipStream_t)stream);
+    if (rc >= 0) return rc;             // -1: shape not covered by the matrix-core kernels
+  }
   return dtype == MTS_F32 ? band_fwd_launch<float>(a, (hipStream_t)stream) : band_fwd_launch<bf16_t>(a, (hipStream_t)stream);
 }
 
@@ -427,5 +413,9 @@ extern "C" int mts_band_attn_bwd(void* stream, int dtype, int B, int L, int D, i
   MTS_CHECK_ARG(qkv && probs && dctx && dqkv && dscores, "mts_band_attn_bwd: null pointer");
   a.qkv = qkv; a.lengths = lengths; a.probs = const_cast<float*>(probs); a.dctx = dctx; a.dqkv = dqkv; a.dscores = dscores;
   a.q_scale = q_scale;
+  if (dtype == MTS_BF16 && g_band_mfma) {
+    rc = mts_band_mfma_bwd(a, (hipStream_t)stream);
+    if (rc >= 0) return rc;
+  }
   return dtype == MTS_F32 ? band_bwd_launch<float>(a, (hipStream_t)stream) : band_bwd_launch<bf16_t>(a, (hipStream_t)stream);
 }

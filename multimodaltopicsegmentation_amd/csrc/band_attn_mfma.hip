@@ -1,0 +1,441 @@
+// Restricted-window ("band") self-attention on the gfx950 matrix cores: bf16 operands, fp32 accumulation.
+// Same semantics and the same ABI buffers as band_attn.hip (probs / dscores fp32 [B*L, heads, slots], slot c of
+// query i <-> key j = i - radius + c); covers head dims that are multiples of 32 and radius <= 63.
+//
+// Work decomposition: one 256-thread workgroup per (document, head, 128 rows); each of the 4 waves owns 32 query
+// rows (32 key rows in the dK/dV pass) and the 16*NKB opposite rows that its band can touch.
+//
+//   qk_phase   T^T[key, query] = sum_d X[key, d] Y[query, d]   (scores: X=K, Y=Q; dP: X=V, Y=dCtx)
+//              both operands are read straight from HBM/L2 in MFMA fragment order (lane = row l&15, 8 consecutive d
+//              at 8*(l>>4)): 16-byte loads, nothing staged.  Computing the TRANSPOSE puts the 16*NKB coefficients of one
+//              query in 4 lanes x (4*NKB) registers, so the softmax needs two cross-lane steps and -- the point of the
+//              transposition -- the accumulator registers are already a valid B operand for the next product.
+//   cv_phase   O^T[d, n] = sum_k R[k, d] C[k, n]                 (ctx: R=V, C=P; dQ: R=K, C=dS; dV: R=dCtx, C=P; dK: R=Q, C=dS)
+//              R rows are staged ONCE per workgroup into LDS by LDS-DMA (global_load_lds, 16 B per lane, no VGPRs) and
+//              read with ds_read_b64_tr_b16 (the transposing LDS read: a lane gets 4 consecutive k for its d column).
+//              The contraction index inside a lane group is permuted (registers of two 16-row accumulator blocks form one
+//              32-deep k-step); the R fragment is fetched with the same permutation, so no data is shuffled.
+//
+// Algorithmic HBM bytes per (row, head), bf16: forward reads q,k,v (6*hd) + writes ctx (2*hd) + probs (4*slots);
+// backward reads q,k,v,dctx (8*hd), probs, writes dqkv (6*hd) + dscores.  The matrix-core work is ~3 us per pass at
+// the BASELINE shape, i.e. the kernels are HBM/L2-latency bound by construction.
+#include "band_common.h"
+
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+#define WROWS 32                 // rows per wave
+#define TROWS (4 * WROWS)        // rows per workgroup
+
+// ---- LDS-DMA staging: image row r <- matrix row clamp(first + r, 0, L-1) of one head's slice; rows are packed (hd*2 bytes).
+// Out-of-document rows are clamped (finite data); their coefficients are exactly 0.
+template <int KK>
+__device__ __forceinline__ void stage_dma(char* img, const bf16_t* __restrict__ doc_base, int ld, int first, int nrows, int L) {
+  constexpr int CPR = 4 * KK;    // 16-byte chunks per row
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int total = nrows * CPR;
+  for (int base = wave * 64; base < total; base += 256) {
+    const int idx = min(base + lane, total - 1);
+    const int r = idx / CPR, ch = idx - r * CPR;
+    const int j = min(max(first + r, 0), L - 1);
+    const bf16_t* src = doc_base + (size_t)j * ld + ch * 8;
+    __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(img + base * 16), 16, 0, 0);
+  }
+}
+
+template <int KK, int NKB>
+__device__ __forceinline__ void qk_phase(const bf16_t* __restrict__ xrows, int ldx, int k0, const bf16_t* __restrict__ yrows, int ldy, int q0,
+                                         int L, int lane, f32x4 (&acc)[NKB][2]) {
+  const int l15 = lane & 15, g = lane >> 4;
+  bf16x8 yq[2][KK];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int row = min(max(q0 + 16 * qb + l15, 0), L - 1);
+    const bf16_t* p = yrows + (size_t)row * ldy + 8 * g;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) yq[qb][kk] = *reinterpret_cast<const bf16x8*>(p + 32 * kk);
+  }
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    const int row = min(max(k0 + 16 * kb + l15, 0), L - 1);
+    const bf16_t* p = xrows + (size_t)row * ldx + 8 * g;
+    bf16x8 xk[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) xk[kk] = *reinterpret_cast<const bf16x8*>(p + 32 * kk);
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) acc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xk[kk], yq[qb][kk], acc[kb][qb], 0, 0, 0);
+  }
+}
+
+// o[db][nb] += sum over the NS k-steps; lo/hi = image rows (incl. the lane group's 4g / 8g part) of elements 0..3 / 4..7
+template <int KK, int NS>
+__device__ __forceinline__ void cv_phase(const char* img, const int (&lo)[NS], const int (&hi)[NS], const bf16x8 (&coef)[NS][2], int lane,
+                                         f32x4 (&o)[2 * KK][2]) {
+  constexpr int RS = 64 * KK;    // row stride in bytes
+  const int r = lane & 15, q = r >> 2, p = r & 3;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const char* plo = img + (lo[s] + q) * RS + 8 * p;
+    const char* phi = img + (hi[s] + q) * RS + 8 * p;
+#pragma unroll
+    for (int db = 0; db < 2 * KK; ++db) {
+      const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(plo + 32 * db));
+      const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(phi + 32 * db));
+      const bf16x8 av = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) o[db][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, coef[s][nb], o[db][nb], 0, 0, 0);
+    }
+  }
+}
+
+// O^T accumulators (lane: row n = n0 + 16 nb + l15, columns 16 db + 4g .. +3) -> out[row][col0 + ...] (8-byte stores)
+template <int KK>
+__device__ __forceinline__ void store_rows(bf16_t* __restrict__ out, int ldo, int n0, int L, int lane, float scale, const f32x4 (&o)[2 * KK][2]) {
+  const int l15 = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int row = n0 + 16 * nb + l15;
+    if (row < L) {
+      bf16_t* p = out + (size_t)row * ldo + 4 * g;
+#pragma unroll
+      for (int db = 0; db < 2 * KK; ++db) {
+        bf16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[db][nb][e] * scale);
+        *reinterpret_cast<bf16x4*>(p + 16 * db) = v;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ float quad_max(float v) {   // over the 4 lane groups that share a query column
+  v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+template <int N>
+__device__ __forceinline__ void zero_acc(f32x4 (&x)[N][2]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) { x[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; x[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int KK, int NKB, int OCC>
+__global__ __launch_bounds__(256, OCC) void band_mfma_fwd_kernel(const BandArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char img[];
+  const int ntiles = (a.L + TROWS - 1) / TROWS;
+  int tile, h, b;
+  decode_block(ntiles, a.heads, ntiles * a.heads * a.B, tile, h, b);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+  const int t0 = tile * TROWS, q0 = t0 + WROWS * wave;
+  const int w = a.radius, W = 2 * w + 1, hd = a.hd, ld = 3 * a.D, L = a.L;
+  const int len = a.lengths ? min(a.lengths[b], L) : L;
+  const bf16_t* qbase = reinterpret_cast<const bf16_t*>(a.qkv) + (size_t)b * L * ld + h * hd;
+
+  stage_dma<KK>(img, qbase + 2 * a.D, ld, t0 - w, TROWS - WROWS + 16 * NKB, L);      // V rows
+
+  f32x4 acc[NKB][2];
+  zero_acc<NKB>(acc);
+  qk_phase<KK, NKB>(qbase + a.D, ld, q0 - w, qbase, ld, q0, L, lane, acc);
+
+  bf16x8 coef[NKB / 2][2];
+  float pr[NKB][2][4];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int i = q0 + 16 * qb + l15;
+    const bool qok = i < len;
+    float m = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int jl = 16 * kb + 4 * g + r, c = jl - 16 * qb - l15, j = q0 - w + jl;
+        const bool ok = qok && c >= 0 && c < W && j >= 0 && j < len;
+        const float s = ok ? acc[kb][qb][r] : -INFINITY;
+        pr[kb][qb][r] = s;
+        m = fmaxf(m, s);
+      }
+    m = quad_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s = pr[kb][qb][r];
+        const float e = (s > -INFINITY) ? __expf(s - m) : 0.f;
+        pr[kb][qb][r] = e;
+        sum += e;
+      }
+    sum = quad_sum(sum);
+    const float inv = qok ? 1.0f / sum : 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pr[kb][qb][r] *= inv;
+#pragma unroll
+    for (int s = 0; s < NKB / 2; ++s) {
+      bf16x8 c8;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { c8[r] = (bf16_t)pr[2 * s][qb][r]; c8[4 + r] = (bf16_t)pr[2 * s + 1][qb][r]; }
+      coef[s][qb] = c8;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the V image (older than every fragment load) has landed
+  __syncthreads();
+  // probabilities for the backward (after the wait so the stores do not sit in front of it)
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int i = q0 + 16 * qb + l15;
+    if (i < L) {
+      float* prow = a.probs + ((size_t)(b * L + i) * a.heads + h) * a.slots;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * kb + 4 * g + r - 16 * qb - l15;
+          if (c >= 0 && c < a.slots) prow[c] = pr[kb][qb][r];
+        }
+    }
+  }
+  f32x4 o[2 * KK][2];
+  zero_acc<2 * KK>(o);
+  int lo[NKB / 2], hi[NKB / 2];
+#pragma unroll
+  for (int s = 0; s < NKB / 2; ++s) { lo[s] = WROWS * wave + 32 * s + 4 * g; hi[s] = lo[s] + 16; }
+  cv_phase<KK, NKB / 2>(img, lo, hi, coef, lane, o);
+  store_rows<KK>(reinterpret_cast<bf16_t*>(a.ctx) + (size_t)b * L * a.D + h * hd, a.D, q0, L, lane, 1.f, o);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward pass A (per query rows): dP = dCtx.V^T, dS = P*(dP - rowsum(P*dP)) (stored), dQ = q_scale * dS.K
+// ------------------------------------------------------------------------------------------------
+template <int KK, int NKB, int OCC>
+__global__ __launch_bounds__(256, OCC) void band_mfma_bwd_q_kernel(const BandArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char img[];
+  const int ntiles = (a.L + TROWS - 1) / TROWS;
+  int tile, h, b;
+  decode_block(ntiles, a.heads, ntiles * a.heads * a.B, tile, h, b);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+  const int t0 = tile * TROWS, q0 = t0 + WROWS * wave;
+  const int w = a.radius, W = 2 * w + 1, hd = a.hd, ld = 3 * a.D, L = a.L;
+  const bf16_t* qbase = reinterpret_cast<const bf16_t*>(a.qkv) + (size_t)b * L * ld + h * hd;
+  const bf16_t* dcbase = reinterpret_cast<const bf16_t*>(a.dctx) + (size_t)b * L * a.D + h * hd;
+
+  stage_dma<KK>(img, qbase + a.D, ld, t0 - w, TROWS - WROWS + 16 * NKB, L);          // K rows
+
+  float pr[NKB][2][4];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int i = q0 + 16 * qb + l15;
+    const float* prow = a.probs + ((size_t)(b * L + min(i, L - 1)) * a.heads + h) * a.slots;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 16 * kb + 4 * g + r - 16 * qb - l15;
+        pr[kb][qb][r] = (i < L && c >= 0 && c < W) ? prow[c] : 0.f;
+      }
+  }
+  f32x4 acc[NKB][2];
+  zero_acc<NKB>(acc);
+  qk_phase<KK, NKB>(qbase + 2 * a.D, ld, q0 - w, dcbase, a.D, q0, L, lane, acc);      // dP^T
+
+  bf16x8 coef[NKB / 2][2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    float delta = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) delta = fmaf(pr[kb][qb][r], acc[kb][qb][r], delta);
+    delta = quad_sum(delta);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pr[kb][qb][r] *= (acc[kb][qb][r] - delta);
+#pragma unroll
+    for (int s = 0; s < NKB / 2; ++s) {
+      bf16x8 c8;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { c8[r] = (bf16_t)pr[2 * s][qb][r]; c8[4 + r] = (bf16_t)pr[2 * s + 1][qb][r]; }
+      coef[s][qb] = c8;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int i = q0 + 16 * qb + l15;
+    if (i < L) {
+      float* dsrow = a.dscores + ((size_t)(b * L + i) * a.heads + h) * a.slots;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * kb + 4 * g + r - 16 * qb - l15;
+          if (c >= 0 && c < a.slots) dsrow[c] = pr[kb][qb][r];
+        }
+    }
+  }
+  f32x4 o[2 * KK][2];
+  zero_acc<2 * KK>(o);
+  int lo[NKB / 2], hi[NKB / 2];
+#pragma unroll
+  for (int s = 0; s < NKB / 2; ++s) { lo[s] = WROWS * wave + 32 * s + 4 * g; hi[s] = lo[s] + 16; }
+  cv_phase<KK, NKB / 2>(img, lo, hi, coef, lane, o);
+  store_rows<KK>(reinterpret_cast<bf16_t*>(a.dqkv) + (size_t)b * L * ld + h * hd, ld, q0, L, lane, a.q_scale, o);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward pass B (per KEY rows): dV = P^T.dCtx, dK = dS^T.Q.  Key j sees queries i = j - w .. j + w; the coefficient
+// of (i, j) sits in slot c = j - i + w of row i.  No atomics: bitwise reproducible.
+// ------------------------------------------------------------------------------------------------
+template <int NS>
+__device__ __forceinline__ void load_coef_T(const float* __restrict__ X, size_t row_stride, int ibase, int j0, int w, int W, int L, int lane,
+                                            bf16x8 (&coef)[NS][2]) {
+  const int l15 = lane & 15, g = lane >> 4;
+  float v[NS][2][8];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int j = j0 + 16 * nb + l15;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int i = ibase + 32 * s + 8 * g + e, c = j - i + w;
+        const bool ok = i >= 0 && i < L && j < L && c >= 0 && c < W;
+        v[s][nb][e] = ok ? X[(size_t)i * row_stride + c] : 0.f;
+      }
+    }
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      bf16x8 c8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) c8[e] = (bf16_t)v[s][nb][e];
+      coef[s][nb] = c8;
+    }
+}
+
+template <int KK, int NKB, int OCC>
+__global__ __launch_bounds__(256, OCC) void band_mfma_bwd_kv_kernel(const BandArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char img[];
+  constexpr int NS = NKB / 2;
+  const int ntiles = (a.L + TROWS - 1) / TROWS;
+  int tile, h, b;
+  decode_block(ntiles, a.heads, ntiles * a.heads * a.B, tile, h, b);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  const int t0 = tile * TROWS, j0 = t0 + WROWS * wave;
+  const int w = a.radius, W = 2 * w + 1, hd = a.hd, ld = 3 * a.D, L = a.L;
+  const bf16_t* qbase = reinterpret_cast<const bf16_t*>(a.qkv) + (size_t)b * L * ld + h * hd;
+  const bf16_t* dcbase = reinterpret_cast<const bf16_t*>(a.dctx) + (size_t)b * L * a.D + h * hd;
+  const size_t xrow = (size_t)a.heads * a.slots;
+  const float* pb = a.probs + ((size_t)b * L * a.heads + h) * a.slots;
+  const float* dsb = a.dscores + ((size_t)b * L * a.heads + h) * a.slots;
+  bf16_t* out = reinterpret_cast<bf16_t*>(a.dqkv) + (size_t)b * L * ld + h * hd;
+  const int nrows = TROWS - WROWS + 16 * NKB;
+
+  int lo[NS], hi[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) { lo[s] = WROWS * wave + 32 * s + 8 * g; hi[s] = lo[s] + 4; }
+  bf16x8 coef[NS][2];
+  f32x4 o[2 * KK][2];
+
+  stage_dma<KK>(img, dcbase, a.D, t0 - w, nrows, L);                                  // dCtx rows
+  load_coef_T<NS>(pb, xrow, j0 - w, j0, w, W, L, lane, coef);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  zero_acc<2 * KK>(o);
+  cv_phase<KK, NS>(img, lo, hi, coef, lane, o);
+  store_rows<KK>(out + 2 * a.D, ld, j0, L, lane, 1.f, o);                              // dV
+
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();                                                                    // every wave is done with the dCtx image
+  stage_dma<KK>(img, qbase, ld, t0 - w, nrows, L);                                    // (scaled) q rows
+  load_coef_T<NS>(dsb, xrow, j0 - w, j0, w, W, L, lane, coef);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  zero_acc<2 * KK>(o);
+  cv_phase<KK, NS>(img, lo, hi, coef, lane, o);
+  store_rows<KK>(out + a.D, ld, j0, L, lane, 1.f, o);                                  // dK
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+template <typename K>
+static int launch(K kernel, const BandArgs& a, int nkb, hipStream_t st, const char* who) {
+  const int nrows = TROWS - WROWS + 16 * nkb;
+  const size_t lds = align_up((size_t)nrows * a.hd * 2, (size_t)1024);      // whole 1-KiB DMA pieces
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { mts_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e)); return MTS_ERR_LAUNCH; }
+  }
+  const int nblocks = ceil_div(a.L, TROWS) * a.heads * a.B;
+  hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(256), lds, st, a);
+  MTS_LAUNCH_CHECK(who);
+  return MTS_OK;
+}
+
+static int pick_nkb(const BandArgs& a) {
+  if (a.hd % 32 != 0 || a.hd > 256) return 0;
+  const int need = 2 + a.slots / 16;
+  return need <= 4 ? 4 : need <= 6 ? 6 : need <= 10 ? 10 : 0;
+}
+
+#define BAND_DISPATCH(KERNEL, NKBV, OCC, ...)                                                         \
+  switch (a.hd / 32) {                                                                                \
+    case 1: return launch(KERNEL<1, NKBV, OCC>, __VA_ARGS__);                                         \
+    case 2: return launch(KERNEL<2, NKBV, OCC>, __VA_ARGS__);                                         \
+    case 4: return launch(KERNEL<4, NKBV, OCC>, __VA_ARGS__);                                         \
+    case 7: return launch(KERNEL<7, NKBV, OCC>, __VA_ARGS__);                                         \
+    case 8: return launch(KERNEL<8, NKBV, OCC>, __VA_ARGS__);                                         \
+    default: return -1;                                                                               \
+  }
+
+template <int WHICH>
+static int dispatch(const BandArgs& a, hipStream_t st, const char* who) {
+  const int nkb = pick_nkb(a);
+  if (nkb == 4) {
+    if (WHICH == 0) { BAND_DISPATCH(band_mfma_fwd_kernel, 4, 2, a, 4, st, who) }
+    if (WHICH == 1) { BAND_DISPATCH(band_mfma_bwd_q_kernel, 4, 2, a, 4, st, who) }
+    if (WHICH == 2) { BAND_DISPATCH(band_mfma_bwd_kv_kernel, 4, 2, a, 4, st, who) }
+  } else if (nkb == 6) {
+    if (WHICH == 0) { BAND_DISPATCH(band_mfma_fwd_kernel, 6, 1, a, 6, st, who) }
+    if (WHICH == 1) { BAND_DISPATCH(band_mfma_bwd_q_kernel, 6, 1, a, 6, st, who) }
+    if (WHICH == 2) { BAND_DISPATCH(band_mfma_bwd_kv_kernel, 6, 1, a, 6, st, who) }
+  } else if (nkb == 10) {
+    if (WHICH == 0) { BAND_DISPATCH(band_mfma_fwd_kernel, 10, 1, a, 10, st, who) }
+    if (WHICH == 1) { BAND_DISPATCH(band_mfma_bwd_q_kernel, 10, 1, a, 10, st, who) }
+    if (WHICH == 2) { BAND_DISPATCH(band_mfma_bwd_kv_kernel, 10, 1, a, 10, st, who) }
+  }
+  return -1;
+}
+
+static bool covered(const BandArgs& a) {
+  const int k = a.hd / 32;
+  return pick_nkb(a) != 0 && (k == 1 || k == 2 || k == 4 || k == 7 || k == 8);
+}
+
+int mts_band_mfma_fwd(const BandArgs& a, hipStream_t st) {
+  if (!covered(a)) return -1;
+  return dispatch<0>(a, st, "mts_band_attn_fwd(mfma)");
+}
+
+int mts_band_mfma_bwd(const BandArgs& a, hipStream_t st) {
+  if (!covered(a)) return -1;
+  int rc = dispatch<1>(a, st, "mts_band_attn_bwd(mfma q)");
+  if (rc) return rc;
+  return dispatch<2>(a, st, "mts_band_attn_bwd(mfma kv)");
+}

@@ -372,11 +372,13 @@ static int g_gemm_glds = -1;
 static int g_tile_mode = -1;
 static int g_force_splits = 0;
 
+void mts_band_set_mfma(int on);   // band_attn.hip
 extern "C" int mts_set_option(const char* key, int value) {
   if (!key) return MTS_ERR_INVALID;
   if (!strcmp(key, "gemm_tile")) { g_tile_mode = value; return MTS_OK; }
   if (!strcmp(key, "gemm_glds")) { g_gemm_glds = value; return MTS_OK; }
   if (!strcmp(key, "gemm_splits")) { g_force_splits = value; return MTS_OK; }
+  if (!strcmp(key, "band_mfma")) { mts_band_set_mfma(value); return MTS_OK; }
   mts_set_error("mts_set_option: unknown key %s", key);
   return MTS_ERR_INVALID;
 }

@@ -235,6 +235,12 @@ def test_gelu_bwd_and_head(ops, dtype):
     (2, 70, 64, 2, 30, [70, 33]),            # two slot blocks (61 slots)
     (1, 40, 448, 2, 15, [1]),                # hd 224 (the BASELINE head dim), a length-1 document
     (2, 33, 64, 4, 4, None),                 # no lengths given
+    # head dims that are multiples of 32: bf16 takes the matrix-core kernels (band_attn_mfma.hip)
+    (2, 300, 448, 2, 15, [300, 131]),        # hd 224, three 128-row tiles, ragged
+    (2, 150, 128, 4, 30, [150, 77]),         # hd 32, 61 slots -> 6 key blocks
+    (1, 200, 128, 2, 63, [170]),             # hd 64, the reference's default window 127 -> 10 key blocks
+    (2, 256, 512, 2, 40, None),              # hd 256, 96 slots
+    (3, 128, 256, 2, 15, [128, 1, 127]),     # hd 128, exactly one tile
 ])
 def test_band_attention_fwd_bwd(ops, dtype, B, Lq, D, heads, radius, lengths):
     hd = D // heads
