@@ -130,10 +130,13 @@ int mts_band_slots(int radius);
 int mts_band_attn_fwd(void* stream, int dtype, int B, int L, int D, int heads, int radius,
                       const void* qkv, const int32_t* lengths, void* ctx, float* probs);
 /* dqkv [B*L, 3D] (dq already multiplied by q_scale so it is the gradient wrt the unscaled projection);
- * dscores: fp32 scratch of the same size as probs. */
+ * dscores: fp32 scratch of the same size as probs.  dbias (optional): fp32 [3D] column sums of dqkv as stored =
+ * the gradient of the q/k/v biases (modeling_longformer.py:504-506), produced from the kernels' output tiles instead of
+ * re-reading dqkv; needs `workspace` of mts_band_attn_bwd_workspace(B, L, D) bytes.  Bitwise reproducible. */
+size_t mts_band_attn_bwd_workspace(int B, int L, int D);
 int mts_band_attn_bwd(void* stream, int dtype, int B, int L, int D, int heads, int radius, float q_scale,
                       const void* qkv, const int32_t* lengths, const float* probs, const void* dctx,
-                      void* dqkv, float* dscores);
+                      void* dqkv, float* dscores, float* dbias, void* workspace);
 
 /* ---------------------------------------------------------------------------------------------
  * Tagger head tail: loss + its gradient, and greedy decode.
@@ -141,10 +144,13 @@ int mts_band_attn_bwd(void* stream, int dtype, int B, int L, int D, int heads, i
  * models/focal_loss.py:38-57, and decode models/CRF.py:362-369.
  * scores: fp32 [B, L, n_out]; targets: fp32 [B, Lt] (pad -1 / 0 as the collater wrote them), Lt >= L;
  * lengths int32 [B].  loss_out: fp32 [2] = {loss, number of rows averaged}.  dscores may be NULL.
+ * workspace: mts_tagger_loss_workspace(B, L) bytes of device scratch for the per-workgroup partial sums
+ * (NULL = single-workgroup path; same result up to fp32 summation order).
  * ------------------------------------------------------------------------------------------- */
+size_t mts_tagger_loss_workspace(int B, int L);
 int mts_tagger_loss(void* stream, int loss_kind, int B, int L, int Lt, int n_out, const float* scores,
                     const float* targets, const int32_t* lengths, float alpha, float gamma,
-                    float* loss_out, float* dscores);
+                    float* loss_out, float* dscores, void* workspace, size_t workspace_bytes);
 /* tags_out: uint8 [B, L]; positions >= length are 0.  prob > threshold, strict. */
 int mts_greedy_decode(void* stream, int B, int L, int n_out, const float* scores, const int32_t* lengths,
                       float threshold, uint8_t* tags_out);

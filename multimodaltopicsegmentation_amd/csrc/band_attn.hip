@@ -17,6 +17,7 @@
 //
 // Semantics (oracle/restatement.py::band_attention; modeling_longformer.py:482-640): key j = i - radius + c
 // takes part iff 0 <= j < len_b; a query i >= len_b yields a zero row.
+#include <algorithm>
 #include "band_common.h"
 
 #define TQ 32
@@ -345,6 +346,7 @@ static int band_fill(BandArgs& a, int dtype, int B, int L, int D, int heads, int
   a.rs = band_row_stride(hd, dtype == MTS_F32 ? 4 : 2);
   a.ps = a.slots + 1;
   a.q_scale = 1.f;
+  a.bias_slab = nullptr; a.img_bytes = 0;
   a.lengths = nullptr; a.qkv = nullptr; a.ctx = nullptr; a.probs = nullptr; a.dctx = nullptr; a.dqkv = nullptr; a.dscores = nullptr;
   return MTS_OK;
 }
@@ -405,17 +407,32 @@ static int band_bwd_launch(const BandArgs& a, hipStream_t st) {
   return MTS_OK;
 }
 
+// norm.hip: out[e] = sum_b partial[b][e] (fixed order)
+int mts_slab_reduce_rows(hipStream_t st, const float* partial, int nblocks, int D, float* out);
+
+extern "C" size_t mts_band_attn_bwd_workspace(int B, int L, int D) {
+  const size_t slab = (size_t)B * ceil_div(L, 128) * 3 * (size_t)D * sizeof(float);
+  return std::max(slab, mts_colsum_workspace(3 * D));
+}
+
 extern "C" int mts_band_attn_bwd(void* stream, int dtype, int B, int L, int D, int heads, int radius, float q_scale, const void* qkv,
-                                 const int32_t* lengths, const float* probs, const void* dctx, void* dqkv, float* dscores) {
+                                 const int32_t* lengths, const float* probs, const void* dctx, void* dqkv, float* dscores, float* dbias,
+                                 void* workspace) {
   BandArgs a;
   int rc = band_fill(a, dtype, B, L, D, heads, radius, "mts_band_attn_bwd");
   if (rc) return rc;
   MTS_CHECK_ARG(qkv && probs && dctx && dqkv && dscores, "mts_band_attn_bwd: null pointer");
+  MTS_CHECK_ARG(!dbias || workspace, "mts_band_attn_bwd: dbias needs mts_band_attn_bwd_workspace() bytes of workspace");
   a.qkv = qkv; a.lengths = lengths; a.probs = const_cast<float*>(probs); a.dctx = dctx; a.dqkv = dqkv; a.dscores = dscores;
   a.q_scale = q_scale;
   if (dtype == MTS_BF16 && g_band_mfma) {
+    a.bias_slab = dbias ? (float*)workspace : nullptr;      // column sums fused into the kernels' output stage
     rc = mts_band_mfma_bwd(a, (hipStream_t)stream);
+    if (rc == MTS_OK && dbias) return mts_slab_reduce_rows((hipStream_t)stream, (const float*)workspace, B * ceil_div(L, 128), 3 * D, dbias);
     if (rc >= 0) return rc;
+    a.bias_slab = nullptr;
   }
-  return dtype == MTS_F32 ? band_bwd_launch<float>(a, (hipStream_t)stream) : band_bwd_launch<bf16_t>(a, (hipStream_t)stream);
+  rc = dtype == MTS_F32 ? band_bwd_launch<float>(a, (hipStream_t)stream) : band_bwd_launch<bf16_t>(a, (hipStream_t)stream);
+  if (rc == MTS_OK && dbias) rc = mts_colsum(stream, dtype, B * L, 3 * D, dqkv, 3 * D, dbias, 0, workspace);
+  return rc;
 }

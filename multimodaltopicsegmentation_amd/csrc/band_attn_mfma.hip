@@ -92,22 +92,51 @@ __device__ __forceinline__ void cv_phase(const char* img, const int (&lo)[NS], c
   }
 }
 
-// O^T accumulators (lane: row n = n0 + 16 nb + l15, columns 16 db + 4g .. +3) -> out[row][col0 + ...] (8-byte stores)
+// O^T accumulators (lane: row n = n0 + 16 nb + l15, columns 16 db + 4g .. +3) -> out[row][0..hd).  The staged-row image is
+// dead once every wave has finished its cv_phase, so each wave parks its 32 x hd tile there (row stride hd*2+16 bytes)
+// and writes it out as whole 16-byte chunks of contiguous rows; with `slab` the column sums of the tile as stored (bf16)
+// are combined over the 4 waves and left in slab[0..hd) -- the q/k/v bias gradient, reduced over tiles by the caller.
 template <int KK>
-__device__ __forceinline__ void store_rows(bf16_t* __restrict__ out, int ldo, int n0, int L, int lane, float scale, const f32x4 (&o)[2 * KK][2]) {
-  const int l15 = lane & 15, g = lane >> 4;
+__device__ __forceinline__ void emit_rows(char* img, float* red, bf16_t* __restrict__ out, int ldo, int n0, int L, float scale,
+                                          const f32x4 (&o)[2 * KK][2], float* __restrict__ slab) {
+  constexpr int HD = 32 * KK, RSO = HD * 2 + 16, CPR = 4 * KK;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+  char* mine = img + wave * WROWS * RSO;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
-    const int row = n0 + 16 * nb + l15;
-    if (row < L) {
-      bf16_t* p = out + (size_t)row * ldo + 4 * g;
+    char* p = mine + (16 * nb + l15) * RSO + 8 * g;
 #pragma unroll
-      for (int db = 0; db < 2 * KK; ++db) {
-        bf16x4 v;
+    for (int db = 0; db < 2 * KK; ++db) {
+      bf16x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[db][nb][e] * scale);
-        *reinterpret_cast<bf16x4*>(p + 16 * db) = v;
+      for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[db][nb][e] * scale);
+      *reinterpret_cast<bf16x4*>(p + 32 * db) = v;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same wave, in-order LDS: the tile is complete
+#pragma unroll
+  for (int it = 0; it < CPR / 2; ++it) {
+    const int idx = it * 64 + lane, r = idx / CPR, ch = idx - r * CPR;
+    const uint4 v = *reinterpret_cast<const uint4*>(mine + r * RSO + ch * 16);
+    if (n0 + r < L) *reinterpret_cast<uint4*>(out + (size_t)(n0 + r) * ldo + ch * 8) = v;
+  }
+  if (slab) {
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (lane < HD / 4) {
+#pragma unroll 8
+      for (int r = 0; r < WROWS; ++r) {
+        const uint2 u = *reinterpret_cast<const uint2*>(mine + r * RSO + lane * 8);
+        cs[0] += bf16_lo(u.x); cs[1] += bf16_hi(u.x); cs[2] += bf16_lo(u.y); cs[3] += bf16_hi(u.y);
       }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[wave * HD + 4 * lane + j] = cs[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < HD) {
+      const int t = threadIdx.x;
+      slab[t] = (red[t] + red[HD + t]) + (red[2 * HD + t] + red[3 * HD + t]);
     }
   }
 }
@@ -213,7 +242,7 @@ __global__ __launch_bounds__(256, OCC) void band_mfma_fwd_kernel(const BandArgs 
 #pragma unroll
   for (int s = 0; s < NKB / 2; ++s) { lo[s] = WROWS * wave + 32 * s + 4 * g; hi[s] = lo[s] + 16; }
   cv_phase<KK, NKB / 2>(img, lo, hi, coef, lane, o);
-  store_rows<KK>(reinterpret_cast<bf16_t*>(a.ctx) + (size_t)b * L * a.D + h * hd, a.D, q0, L, lane, 1.f, o);
+  emit_rows<KK>(img, nullptr, reinterpret_cast<bf16_t*>(a.ctx) + (size_t)b * L * a.D + h * hd, a.D, q0, L, 1.f, o, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -293,7 +322,9 @@ __global__ __launch_bounds__(256, OCC) void band_mfma_bwd_q_kernel(const BandArg
 #pragma unroll
   for (int s = 0; s < NKB / 2; ++s) { lo[s] = WROWS * wave + 32 * s + 4 * g; hi[s] = lo[s] + 16; }
   cv_phase<KK, NKB / 2>(img, lo, hi, coef, lane, o);
-  store_rows<KK>(reinterpret_cast<bf16_t*>(a.dqkv) + (size_t)b * L * ld + h * hd, ld, q0, L, lane, a.q_scale, o);
+  float* red = reinterpret_cast<float*>(img + a.img_bytes);
+  float* slab = a.bias_slab ? a.bias_slab + (size_t)(b * ntiles + tile) * ld + h * hd : nullptr;
+  emit_rows<KK>(img, red, reinterpret_cast<bf16_t*>(a.dqkv) + (size_t)b * L * ld + h * hd, ld, q0, L, a.q_scale, o, slab);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -358,7 +389,9 @@ __global__ __launch_bounds__(256, OCC) void band_mfma_bwd_kv_kernel(const BandAr
   __syncthreads();
   zero_acc<2 * KK>(o);
   cv_phase<KK, NS>(img, lo, hi, coef, lane, o);
-  store_rows<KK>(out + 2 * a.D, ld, j0, L, lane, 1.f, o);                              // dV
+  float* red = reinterpret_cast<float*>(img + a.img_bytes);
+  float* slab = a.bias_slab ? a.bias_slab + (size_t)(b * ntiles + tile) * ld + h * hd : nullptr;
+  emit_rows<KK>(img, red, out + 2 * a.D, ld, j0, L, 1.f, o, slab ? slab + 2 * a.D : nullptr);      // dV
 
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();                                                                    // every wave is done with the dCtx image
@@ -368,16 +401,17 @@ __global__ __launch_bounds__(256, OCC) void band_mfma_bwd_kv_kernel(const BandAr
   __syncthreads();
   zero_acc<2 * KK>(o);
   cv_phase<KK, NS>(img, lo, hi, coef, lane, o);
-  store_rows<KK>(out + a.D, ld, j0, L, lane, 1.f, o);                                  // dK
+  emit_rows<KK>(img, red, out + a.D, ld, j0, L, 1.f, o, slab ? slab + a.D : nullptr);              // dK
 }
 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 template <typename K>
-static int launch(K kernel, const BandArgs& a, int nkb, hipStream_t st, const char* who) {
+static int launch(K kernel, BandArgs a, int nkb, hipStream_t st, const char* who) {
   const int nrows = TROWS - WROWS + 16 * nkb;
-  const size_t lds = align_up((size_t)nrows * a.hd * 2, (size_t)1024);      // whole 1-KiB DMA pieces
+  a.img_bytes = (int)align_up((size_t)nrows * a.hd * 2, (size_t)1024);      // whole 1-KiB DMA pieces
+  const size_t lds = (size_t)a.img_bytes + 4 * (size_t)a.hd * sizeof(float);  // + the 4 waves' column sums
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { mts_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e)); return MTS_ERR_LAUNCH; }

@@ -10,6 +10,8 @@ struct BandArgs {
   int rs;      // LDS row stride (bytes) of staged q/k/v rows
   int ps;      // LDS row stride (floats) of the probability tile
   float q_scale;
+  float* bias_slab;   // MFMA backward: per-(document, 128-row tile) column sums of dqkv, [B*ceil(L/128)][3D], or NULL
+  int img_bytes;      // MFMA kernels: size of the staged-row LDS image
 };
 
 __host__ __device__ inline int band_slots(int radius) { return ((2 * radius + 1 + 31) / 32) * 32; }

@@ -253,27 +253,49 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs a, const S
 // column sums (bias gradients): two deterministic stages
 // ------------------------------------------------------------------------------------------------
 #define COLSUM_RS 128
+// workgroup = 64 columns (16 lanes x 4) x 16 row lanes over one slice of rows; 4 independent loads in flight per lane,
+// the 16 row lanes are combined through LDS in a fixed order
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ X, int M, int N, int ldx,
                                                              float* __restrict__ partial) {
-  const int n = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (n >= N) return;
+  __shared__ float red[16][64];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int n = blockIdx.x * 64 + cx * 4;
   const int rs = blockIdx.y;
   const int rows_per = (M + COLSUM_RS - 1) / COLSUM_RS;
   const int m0 = rs * rows_per, m1 = min(M, m0 + rows_per);
   float s[4] = {0.f, 0.f, 0.f, 0.f};
   if (n + 3 < N) {
-    for (int m = m0; m < m1; ++m) {
+    int m = m0 + ry;
+    for (; m + 48 < m1; m += 64) {
+      float v[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) load4<T>(X + (size_t)(m + 16 * u) * ldx + n, v[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i] += v[u][i];
+    }
+    for (; m < m1; m += 16) {
       float v[4];
       load4<T>(X + (size_t)m * ldx + n, v);
 #pragma unroll
       for (int i = 0; i < 4; ++i) s[i] += v[i];
     }
-  } else {
-    for (int m = m0; m < m1; ++m)
+  } else if (n < N) {
+    for (int m = m0 + ry; m < m1; m += 16)
       for (int i = 0; i < 4 && n + i < N; ++i) s[i] += to_f32(X[(size_t)m * ldx + n + i]);
   }
-  for (int i = 0; i < 4 && n + i < N; ++i) partial[(size_t)rs * N + n + i] = s[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) red[ry][cx * 4 + i] = s[i];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int c = threadIdx.x, nn = blockIdx.x * 64 + c;
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += red[r][c];
+    if (nn < N) partial[(size_t)rs * N + nn] = t;
+  }
 }
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int N, int nparts,
                                                            float* __restrict__ out, int accumulate) {
@@ -336,7 +358,7 @@ extern "C" int mts_colsum(void* stream, int dtype, int M, int N, const void* X, 
   MTS_CHECK_ARG(ldx % 4 == 0, "mts_colsum: ldx must be a multiple of 4");
   hipStream_t st = (hipStream_t)stream;
   const int nparts = min(COLSUM_RS, M);
-  dim3 grid(ceil_div(ceil_div(N, 4), 256), COLSUM_RS);
+  dim3 grid(ceil_div(N, 64), COLSUM_RS);
   // rows_per = ceil(M / RS): slices past M write zeros (m0 >= m1), so all RS partials are defined
   (void)nparts;
   if (dtype == MTS_F32)
@@ -367,6 +389,7 @@ extern "C" int mts_cast(void* stream, int dst_dtype, const float* src, void* dst
 }
 
 int mts_launch_gemm256(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st);   // gemm256.hip
+int mts_launch_gemm224(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st);   // gemm224.hip
 
 static int g_gemm_glds = -1;
 static int g_tile_mode = -1;
@@ -452,15 +475,18 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
   const double bw = 3500.0;     // slab MB per us
   double best = 1e30;
   int splits = 1;
-  bool use256 = false;
-  for (int big = 0; big <= (can256 ? 1 : 0); ++big) {
-    if (tile_mode == 256 && can256 && !big) continue;
+  int use256 = 0;               // 0: 128x128 kernel, 1: 256x256, 2: 256x224 (N a multiple of 224: d = 1792 projections)
+  const bool can224 = can256 && (N % 224 == 0) && tile_mode != 256;
+  for (int big = 0; big <= (can256 ? 2 : 0); ++big) {
+    if (big == 2 && !can224) continue;
+    if (tile_mode == 256 && can256 && big != 1) continue;
+    if (tile_mode == 224 && can224 && big != 2) continue;
     const int tile = big ? 256 : 128;
     // measured on MI355X (tools/gemm_ksweep.py, gemm_sweep.py): us per K element per round of workgroups, and per-round fixed cost
     const double slots = big ? 256.0 : 512.0;
-    const double t_k = big ? (layout == MTS_TN ? 0.0353 : 0.0232) : (layout == MTS_TN ? 0.0170 : 0.0180);
+    const double t_k = (big ? (layout == MTS_TN ? 0.0353 : 0.0232) : (layout == MTS_TN ? 0.0170 : 0.0180)) * (big == 2 ? 0.875 : 1.0);
     const double t_0 = big ? 7.7 : 6.5;
-    const int nt = ceil_div(M, tile) * ceil_div(N, tile);
+    const int nt = ceil_div(M, tile) * (big == 2 ? N / 224 : ceil_div(N, tile));
     for (int sp = 1; sp <= (can_split ? 32 : 1); ++sp) {
       const int ks = ceil_div(ceil_div(K, sp), BK) * BK;
       if (ceil_div(K, ks) != sp) continue;
@@ -477,7 +503,7 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
     a.slab = (float*)workspace;
   }
   if (use256) {
-    int rc = mts_launch_gemm256(a, layout, c_dtype == MTS_F32, splits, st);
+    int rc = use256 == 2 ? mts_launch_gemm224(a, layout, c_dtype == MTS_F32, splits, st) : mts_launch_gemm256(a, layout, c_dtype == MTS_F32, splits, st);
     if (rc) return rc;
   } else if (c_dtype == MTS_F32) {
     if (layout == MTS_NT) launch_bf16<MTS_NT, float>(a, splits, st);

@@ -1,0 +1,281 @@
+// 256x224x64 variant of the big-tile bf16 MFMA GEMM (gemm256.hip) for N that is a multiple of 224.
+//
+// Why: the reference's width is d = 1792 = 8 x 224 (768-d sentence + 1024-d audio embeddings), so every projection of
+// the tagger has N in {1792, 5376}.  With 256-wide tiles those give 448 / 1344 output tiles = 1.75 / 5.25 rounds over
+// the 256 CUs -- the last round is 3/4 or 1/4 full.  224-wide tiles give 512 / 1536 tiles = exactly 2 / 6 rounds, each
+// 12.5 % shorter.
+//
+// Same pipeline as gemm256.hip (two K-tile buffers of four 16-KiB half images, LDS-DMA one K-tile ahead for A and two
+// for B behind a counted vmcnt, raw s_barrier), but the 8 waves are laid out 4 (M) x 2 (N): wave (wm, wn) owns C rows
+// wm*64..+63 (half of A[wm>>1]) and cols wn*112..+111 (all of B[wn]; a B half image holds 112 used rows, the DMA still
+// moves 128 so that every wave issues the same number of loads and one counted wait serves all):
+//     phase 1: DMA A0(t+1) ; read A[rows 0..31], B[cols 0..63]   ; 16 MFMA  (0,0)
+//     phase 2: DMA A1(t+1) ; read B[cols 64..111]                ; 12 MFMA  (0,1) ; barrier
+//     phase 3: DMA B0(t+2) ; read A[rows 32..63]                 ; 12 MFMA  (1,1)
+//     phase 4: DMA B1(t+2) ;                                       16 MFMA  (1,0) ; vmcnt(4) ; barrier
+#include <algorithm>
+#include <math.h>
+#include "gemm_common.h"
+
+#define HT_BYTES 16384
+#define BUF_BYTES (4 * HT_BYTES)
+#define LDS_TOTAL (2 * BUF_BYTES + 8 * 4096)
+#define BN224 224
+#define HN224 112
+
+template <bool KMAJOR>
+__device__ __forceinline__ void dma_half(const bf16_t* __restrict__ G, int ld, int row0, int dim, int k0, char* dst, int wave_u, int lane) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int piece = wave_u * 2 + i;   // 16 pieces of 1 KiB, 2 per wave
+    const bf16_t* src;
+    if constexpr (KMAJOR) {
+      const int row = piece * 8 + (lane >> 3), pos = lane & 7;
+      const int ch = pos ^ ((row >> 1) & 7);
+      src = G + (size_t)min(row0 + row, dim - 1) * ld + k0 + ch * 8;
+    } else {
+      const int kr = piece * 4 + (lane >> 4), c16 = lane & 15;
+      const int ch = ((((c16 >> 1) ^ strided_key(kr))) << 1) | (c16 & 1);
+      src = G + (size_t)(k0 + kr) * ld + min(row0 + ch * 8, dim - 8);
+    }
+    __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(dst + piece * 1024), 16, 0, 0);
+  }
+}
+
+// C tile of one wave (64 x 112) -> global; bf16 output through a wave-private LDS staging area, 16 rows at a time, so that
+// HBM sees 16-byte pieces of contiguous 224-byte row segments instead of the 8-byte pieces of the accumulator layout.
+template <typename TC>
+__device__ __forceinline__ void store_tile_224(const GemmArgs& a, f32x4 (&acc)[4][7], int m0, int n0, bool first_slice, char* stage,
+                                               int lane) {
+  const int r16 = lane & 15, g = lane >> 4;
+  const bool vec_ok = (a.N % 8 == 0) && (a.ldc % 8 == 0);
+  if constexpr (sizeof(TC) == 2) {
+    if (!a.slab && vec_ok) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + i * 16 + r16;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+          const int n = n0 + j * 16 + 4 * g;
+          float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          if (m < a.M && n < a.N) epi_math4<bf16_t>(a, m, n, v, first_slice);
+          uint2 pk;
+          pk.x = pack_bf16x2(v[0], v[1]);
+          pk.y = pack_bf16x2(v[2], v[3]);
+          *reinterpret_cast<uint2*>(stage + r16 * 240 + (j * 16 + 4 * g) * 2) = pk;      // 240-byte rows: 16 B of padding
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int idx = it * 64 + lane;
+          if (idx < 16 * 14) {
+            const int row = idx / 14, ch = idx - row * 14;
+            const uint4 val = *reinterpret_cast<const uint4*>(stage + row * 240 + ch * 16);
+            const int mm = m0 + i * 16 + row, n = n0 + ch * 8;
+            if (mm < a.M && n < a.N) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + (size_t)mm * a.ldc + n) = val;
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + i * 16 + r16;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int n = n0 + j * 16 + 4 * g;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      epilogue4<bf16_t, TC>(a, m, n, v, first_slice);
+    }
+  }
+}
+
+template <int LAYOUT, typename TC>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a) {
+  constexpr bool A_KMAJOR = (LAYOUT != MTS_TN);
+  constexpr bool B_KMAJOR = (LAYOUT == MTS_NT);
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A0 | A1 | B0 | B1] + 8 x 4 KiB store staging
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave_u >> 1, wn = wave_u & 1;
+  const int r16 = lane & 15, g = lane >> 4;
+  char* stage = smem + 2 * BUF_BYTES + wave_u * 4096;
+
+  const int ntn = a.N / BN224;
+  const int ntm = (a.M + 255) / 256;
+  const int nt = ntn * ntm;
+  const int kbeg = blockIdx.z * a.ksplit;
+  const int kend = min(a.K, kbeg + a.ksplit);
+  const int nk = (kend - kbeg) / BK;
+  const bool first_slice = (blockIdx.z == 0);
+
+  const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(a.A);
+  const bf16_t* __restrict__ B = reinterpret_cast<const bf16_t*>(a.B);
+
+  auto tile_origin = [&](int t, int& bm0, int& bn0) {
+    const int q = nt >> 3, rr = nt & 7, xcd = t & 7, idx = t >> 3;
+    const int id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    bm0 = (id / ntn) * 256;
+    bn0 = (id % ntn) * BN224;
+  };
+  int bm0, bn0;
+  auto dmaA = [&](int h, int kt) {
+    dma_half<A_KMAJOR>(A, a.lda, bm0 + h * 128, a.M, kbeg + kt * BK, smem + (kt & 1) * BUF_BYTES + h * HT_BYTES, wave_u, lane);
+  };
+  auto dmaB = [&](int h, int kt) {
+    dma_half<B_KMAJOR>(B, a.ldb, bn0 + h * HN224, a.N, kbeg + kt * BK, smem + (kt & 1) * BUF_BYTES + (2 + h) * HT_BYTES, wave_u, lane);
+  };
+  auto prologue = [&]() {
+    if (nk > 0) {
+      dmaB(0, 0); dmaB(1, 0); dmaA(0, 0); dmaA(1, 0);
+      if (nk > 1) { dmaB(0, 1); dmaB(1, 1); }
+    }
+  };
+
+  f32x4 acc[4][7];
+  bf16x8 af[2][2], b0[4][2], b1[3][2];
+  const int arow = (wm & 1) * 64;
+
+  int t = blockIdx.x;
+  if (t >= nt) return;
+  tile_origin(t, bm0, bn0);
+  prologue();
+  if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // (A register-pipelined variant -- fragments of phase p+1 fetched from LDS under the MFMAs of phase p, second barrier
+  // moved up so that the next K-tile's first fragments are fetched in phase 4 -- measured 5-15 % SLOWER than this simple
+  // form on MI355X, so LDS latency is not what holds the K-tile at ~2x its pure MFMA time; see DESIGN.md.)
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 7; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* At = smem + (kt & 1) * BUF_BYTES + (wm >> 1) * HT_BYTES;
+      const char* Bt = smem + (kt & 1) * BUF_BYTES + (2 + wn) * HT_BYTES;
+
+      // ---- phase 1 ---------------------------------------------------------------------------
+      if (kt + 1 < nk) dmaA(0, kt + 1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if constexpr (B_KMAJOR) b0[j][ks] = frag_kmajor(Bt, j * 16 + r16, ks * 4 + g);
+          else b0[j][ks] = frag_strided(Bt, ks * 32 + 8 * g, j * 16, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          if constexpr (A_KMAJOR) af[i][ks] = frag_kmajor(At, arow + i * 16 + r16, ks * 4 + g);
+          else af[i][ks] = frag_strided(At, ks * 32 + 8 * g, arow + i * 16, lane);
+        }
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j][ks], af[i][ks], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+
+      // ---- phase 2 ---------------------------------------------------------------------------
+      if (kt + 1 < nk) dmaA(1, kt + 1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          if constexpr (B_KMAJOR) b1[j][ks] = frag_kmajor(Bt, 64 + j * 16 + r16, ks * 4 + g);
+          else b1[j][ks] = frag_strided(Bt, ks * 32 + 8 * g, 64 + j * 16, lane);
+        }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) acc[i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j][ks], af[i][ks], acc[i][4 + j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();          // every wave is done reading this buffer's B images
+
+      // ---- phase 3 ---------------------------------------------------------------------------
+      if (kt + 2 < nk) dmaB(0, kt + 2);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          if constexpr (A_KMAJOR) af[i][ks] = frag_kmajor(At, arow + 32 + i * 16 + r16, ks * 4 + g);
+          else af[i][ks] = frag_strided(At, ks * 32 + 8 * g, arow + 32 + i * 16, lane);
+        }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) acc[2 + i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j][ks], af[i][ks], acc[2 + i][4 + j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+
+      // ---- phase 4 ---------------------------------------------------------------------------
+      if (kt + 2 < nk) dmaB(1, kt + 2);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j][ks], af[i][ks], acc[2 + i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but B(kt+2) have landed
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+
+    const int m0 = bm0 + wm * 64, n0 = bn0 + wn * HN224;
+    t += gridDim.x;
+    const bool more = t < nt;
+    if (more) {
+      tile_origin(t, bm0, bn0);
+      prologue();
+    }
+    store_tile_224<TC>(a, acc, m0, n0, first_slice, stage, lane);
+    if (!more) break;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // stores are younger than the DMAs: wait for everything
+    __builtin_amdgcn_s_barrier();
+  }
+}
+
+template <int LAYOUT, typename TC>
+static int launch_one(const GemmArgs& a, int splits, hipStream_t st) {
+  auto k = gemm_bf16_224_kernel<LAYOUT, TC>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    if (e != hipSuccess) { mts_set_error("gemm224: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MTS_ERR_LAUNCH; }
+    attr_set = true;
+  }
+  const int nt = ceil_div(a.M, 256) * (a.N / BN224);
+  const int gx = (splits == 1) ? std::min(nt, 256) : nt;
+  hipLaunchKernelGGL(k, dim3(gx, 1, splits), dim3(512), LDS_TOTAL, st, a);
+  return MTS_OK;
+}
+
+// called from mts_gemm (gemm.hip) when N is a multiple of 224 and the 224-wide tiling fills the CUs better
+int mts_launch_gemm224(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st) {
+  if (c_is_f32) {
+    if (layout == MTS_NT) return launch_one<MTS_NT, float>(a, splits, st);
+    if (layout == MTS_NN) return launch_one<MTS_NN, float>(a, splits, st);
+    return launch_one<MTS_TN, float>(a, splits, st);
+  }
+  if (layout == MTS_NT) return launch_one<MTS_NT, bf16_t>(a, splits, st);
+  if (layout == MTS_NN) return launch_one<MTS_NN, bf16_t>(a, splits, st);
+  return launch_one<MTS_TN, bf16_t>(a, splits, st);
+}

@@ -1,5 +1,7 @@
 // Tagger tail: masked loss (+ its gradient wrt the scores) and greedy decode.
-// Tiny tensors ([B, L, n_out]): one workgroup, everything in one launch, deterministic tree reductions.
+// Small tensors ([B, L, n_out]) but transcendental-heavy: 2048 rows per workgroup, per-workgroup partial sums added in a
+// fixed order by a one-wave kernel (bitwise reproducible).
+#include <algorithm>
 #include "common.h"
 
 __device__ __forceinline__ float block_sum_1024(float v, float* red) {
@@ -46,51 +48,88 @@ __device__ __forceinline__ float bce_elem(float x, float y, float& grad) {
   return -(y * lp + (1.f - y) * l1p);
 }
 
-__global__ __launch_bounds__(1024) void tagger_loss_kernel(int kind, int B, int L, int Lt, int n_out, const float* __restrict__ scores,
+__global__ __launch_bounds__(256) void tagger_loss_kernel(int kind, int B, int L, int Lt, int n_out, const float* __restrict__ scores,
                                                            const float* __restrict__ targets, const int32_t* __restrict__ lengths,
-                                                           float alpha, float gamma, float* __restrict__ loss_out, float* __restrict__ dscores) {
+                                                           float alpha, float gamma, float* __restrict__ loss_out, float* __restrict__ dscores,
+                                                           float* __restrict__ partial) {
+  // gridDim.x > 1: every workgroup recomputes the (cheap) row count, handles an interleaved share of the rows and leaves
+  // its partial loss sum in partial[blockIdx.x]; tagger_loss_final_kernel adds them in a fixed order.
   __shared__ float red[16];
   const int N = B * L;
+  constexpr int U = 2;                          // rows per thread per batch: their loads are issued together
+  const int step = blockDim.x * U;
   // pass 1: number of rows that are averaged
   float cnt = 0.f;
-  for (int r = threadIdx.x; r < N; r += blockDim.x) {
-    const int b = r / L, i = r % L;
-    if (kind == MTS_LOSS_CE) cnt += (targets[(size_t)b * Lt + i] != -1.f) ? 1.f : 0.f;            // ignore_index = -1 (CRF.py:298)
-    else cnt += (i < (lengths ? lengths[b] : L)) ? 1.f : 0.f;                                        // un-pad loop (CRF.py:348-350)
+  if (kind == MTS_LOSS_CE) {                    // ignore_index = -1 (CRF.py:298)
+    for (int base = threadIdx.x; base < N; base += step) {
+      float y[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int r = base + u * blockDim.x;
+        y[u] = (r < N) ? targets[(size_t)(r / L) * Lt + r % L] : -1.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) cnt += (y[u] != -1.f) ? 1.f : 0.f;
+    }
+  } else {                                      // un-pad loop (CRF.py:348-350): rows i < len_b
+    for (int b = threadIdx.x; b < B; b += blockDim.x) cnt += (float)(lengths ? min(max(lengths[b], 0), L) : L);
   }
   cnt = block_sum_1024(cnt, red);
   const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
   float acc = 0.f;
-  for (int r = threadIdx.x; r < N; r += blockDim.x) {
-    const int b = r / L, i = r % L;
-    const float y = targets[(size_t)b * Lt + i];
-    if (kind == MTS_LOSS_CE) {
-      const float x0 = scores[(size_t)r * 2], x1 = scores[(size_t)r * 2 + 1];
-      float g0 = 0.f, g1 = 0.f;
-      if (y != -1.f) {
-        const float m = fmaxf(x0, x1);
-        const float lse = m + logf(expf(x0 - m) + expf(x1 - m));
-        const int t = (int)y;
-        acc += lse - (t == 0 ? x0 : x1);
-        const float p0 = expf(x0 - lse), p1 = expf(x1 - lse);
-        g0 = (p0 - (t == 0 ? 1.f : 0.f)) * inv;
-        g1 = (p1 - (t == 1 ? 1.f : 0.f)) * inv;
+  for (int base = blockIdx.x * step + threadIdx.x; base < N; base += gridDim.x * step) {
+    float y[U], x0[U], x1[U];
+    int len[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = base + u * blockDim.x;
+      const bool in = r < N;
+      const int b = in ? r / L : 0, i = in ? r % L : 0;
+      y[u] = in ? targets[(size_t)b * Lt + i] : -1.f;
+      len[u] = in ? (lengths ? lengths[b] : L) : 0;
+      if (kind == MTS_LOSS_CE) { x0[u] = in ? scores[(size_t)r * 2] : 0.f; x1[u] = in ? scores[(size_t)r * 2 + 1] : 0.f; }
+      else { x0[u] = in ? scores[r] : 0.f; x1[u] = 0.f; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = base + u * blockDim.x;
+      if (r >= N) continue;
+      const int i = r % L;
+      if (kind == MTS_LOSS_CE) {
+        float g0 = 0.f, g1 = 0.f;
+        if (y[u] != -1.f) {
+          const float m = fmaxf(x0[u], x1[u]);
+          const float lse = m + logf(expf(x0[u] - m) + expf(x1[u] - m));
+          const int t = (int)y[u];
+          acc += lse - (t == 0 ? x0[u] : x1[u]);
+          const float p0 = expf(x0[u] - lse), p1 = expf(x1[u] - lse);
+          g0 = (p0 - (t == 0 ? 1.f : 0.f)) * inv;
+          g1 = (p1 - (t == 1 ? 1.f : 0.f)) * inv;
+        }
+        if (dscores) { dscores[(size_t)r * 2] = g0; dscores[(size_t)r * 2 + 1] = g1; }
+      } else {
+        float g = 0.f;
+        if (i < len[u]) {
+          float gr;
+          acc += (kind == MTS_LOSS_FOCAL) ? focal_elem(x0[u], y[u], alpha, gamma, gr) : bce_elem(x0[u], y[u], gr);
+          g = gr * inv;
+        }
+        if (dscores) dscores[r] = g;
       }
-      if (dscores) { dscores[(size_t)r * 2] = g0; dscores[(size_t)r * 2 + 1] = g1; }
-    } else {
-      const bool valid = i < (lengths ? lengths[b] : L);
-      float g = 0.f;
-      if (valid) {
-        const float x = scores[r];
-        float gr;
-        acc += (kind == MTS_LOSS_FOCAL) ? focal_elem(x, y, alpha, gamma, gr) : bce_elem(x, y, gr);
-        g = gr * inv;
-      }
-      if (dscores) dscores[r] = g;
     }
   }
   acc = block_sum_1024(acc, red);
-  if (threadIdx.x == 0) { loss_out[0] = acc * inv; loss_out[1] = cnt; }
+  if (threadIdx.x == 0) {
+    if (gridDim.x == 1) { loss_out[0] = acc * inv; loss_out[1] = cnt; }
+    else { partial[blockIdx.x] = acc; if (blockIdx.x == 0) loss_out[1] = cnt; }
+  }
+}
+
+__global__ __launch_bounds__(64) void tagger_loss_final_kernel(int nblocks, const float* __restrict__ partial, float* __restrict__ loss_out) {
+  float s = 0.f;
+  for (int b = threadIdx.x; b < nblocks; b += 64) s += partial[b];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) { const float cnt = loss_out[1]; loss_out[0] = cnt > 0.f ? s * (1.f / cnt) : 0.f; }
 }
 
 __global__ __launch_bounds__(256) void greedy_decode_kernel(int B, int L, int n_out, const float* __restrict__ scores,
@@ -110,14 +149,21 @@ __global__ __launch_bounds__(256) void greedy_decode_kernel(int B, int L, int n_
   tags[r] = (valid && p > threshold) ? 1 : 0;
 }
 
+extern "C" size_t mts_tagger_loss_workspace(int B, int L) { return (size_t)std::min(1024, ceil_div(B * L, 256 * 2)) * sizeof(float); }
+
 extern "C" int mts_tagger_loss(void* stream, int loss_kind, int B, int L, int Lt, int n_out, const float* scores, const float* targets,
-                               const int32_t* lengths, float alpha, float gamma, float* loss_out, float* dscores) {
+                               const int32_t* lengths, float alpha, float gamma, float* loss_out, float* dscores, void* workspace,
+                               size_t workspace_bytes) {
   MTS_CHECK_ARG(B > 0 && L > 0 && Lt >= L && scores && targets && loss_out, "mts_tagger_loss: bad arguments");
   MTS_CHECK_ARG(loss_kind == MTS_LOSS_CE || loss_kind == MTS_LOSS_BCE || loss_kind == MTS_LOSS_FOCAL,
                 "Choose one of CrossEntropy or BinaryCrossEntropy as loss function");   /* models/CRF.py:312 */
   MTS_CHECK_ARG((loss_kind == MTS_LOSS_CE) ? n_out == 2 : n_out == 1, "mts_tagger_loss: n_out=%d does not match the loss kind", n_out);
-  hipLaunchKernelGGL(tagger_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, loss_kind, B, L, Lt, n_out, scores, targets, lengths,
-                     alpha, gamma, loss_out, dscores);
+  // 256 threads x 8 rows per workgroup; one workgroup (no workspace needed) up to 2048 rows
+  const int nblocks = (int)std::min<size_t>(ceil_div(B * L, 256 * 2), workspace ? workspace_bytes / sizeof(float) : 1);
+  const int grid = std::max(1, std::min(nblocks, 1024));
+  hipLaunchKernelGGL(tagger_loss_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, loss_kind, B, L, Lt, n_out, scores, targets, lengths,
+                     alpha, gamma, loss_out, dscores, (float*)workspace);
+  if (grid > 1) hipLaunchKernelGGL(tagger_loss_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, grid, (const float*)workspace, loss_out);
   MTS_LAUNCH_CHECK("mts_tagger_loss");
   return MTS_OK;
 }

@@ -183,20 +183,13 @@ __global__ __launch_bounds__(256) void head_bwd_data_kernel(const float* __restr
 //   MODE 0: LayerNorm backward.  MODE 1: head parameter gradient (slots 0..n_out-1 = dw rows; db via slot 4.. see below)
 // ------------------------------------------------------------------------------------------------
 template <typename T, int NV>
-__global__ __launch_bounds__(64 * ROW_WAVES) void ln_bwd_kernel(
+__global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
     const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ dlogit, const float* __restrict__ head_w, int n_out,
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd, int rows, int D,
     T* __restrict__ dx, float* __restrict__ partial) {
   __shared__ float red[ROW_WAVES][3][64 * 4];   // one vector slot at a time is combined through LDS
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  float g_[NV][4];
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int e = 4 * (lane + 64 * i);
-    if (e < D) load4<float>(gamma + e, g_[i]);
-    else { g_[i][0] = g_[i][1] = g_[i][2] = g_[i][3] = 0.f; }
-  }
   float dg[NV][4], db[NV][4], dxs[NV][4];
 #pragma unroll
   for (int i = 0; i < NV; ++i)
@@ -204,7 +197,23 @@ __global__ __launch_bounds__(64 * ROW_WAVES) void ln_bwd_kernel(
     for (int j = 0; j < 4; ++j) dg[i][j] = db[i][j] = dxs[i][j] = 0.f;
 
   const float invD = 1.0f / (float)D;
-  for (int row = blockIdx.x * ROW_WAVES + wave; row < rows; row += gridDim.x * ROW_WAVES) {
+  // the next row's x / dy are fetched (raw, storage precision) before the current row is reduced, so a wave always has
+  // a full row of loads in flight behind its arithmetic and its stores
+  const int stride = gridDim.x * ROW_WAVES;
+  int row = blockIdx.x * ROW_WAVES + wave;
+  Pack<T, 4> px[NV], pd[NV];
+  auto fetch = [&](int r) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = 4 * (lane + 64 * i);
+      if (e < D) {
+        px[i].load(x + (size_t)r * D + e);
+        if (dy) pd[i].load(dy + (size_t)r * D + e);
+      }
+    }
+  };
+  if (row < rows) fetch(row);
+  for (; row < rows; row += stride) {
     const float mu = mean[row], rs = rstd[row];
     float xh[NV][4], gy[NV][4];
     float s1 = 0.f, s2 = 0.f;
@@ -214,9 +223,19 @@ __global__ __launch_bounds__(64 * ROW_WAVES) void ln_bwd_kernel(
     for (int i = 0; i < NV; ++i) {
       const int e = 4 * (lane + 64 * i);
       if (e < D) {
-        float xv[4], dv[4] = {0.f, 0.f, 0.f, 0.f};
-        load4<T>(x + (size_t)row * D + e, xv);
-        if (dy) load4<T>(dy + (size_t)row * D + e, dv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { xh[i][j] = px[i].get(j); gy[i][j] = dy ? pd[i].get(j) : 0.f; }
+      }
+    }
+    if (row + stride < rows) fetch(row + stride);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = 4 * (lane + 64 * i);
+      if (e < D) {
+        float dv[4], gv[4];
+        load4<float>(gamma + e, gv);          // L1/L2-resident; keeping gamma in registers would cost NV*4 VGPRs
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dv[j] = gy[i][j];
         if (head_w) {
           for (int c = 0; c < n_out; ++c) {
             float wv[4];
@@ -227,8 +246,8 @@ __global__ __launch_bounds__(64 * ROW_WAVES) void ln_bwd_kernel(
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          xh[i][j] = (xv[j] - mu) * rs;
-          gy[i][j] = dv[j] * g_[i][j];
+          xh[i][j] = (xh[i][j] - mu) * rs;
+          gy[i][j] = dv[j] * gv[j];
           s1 += gy[i][j];
           s2 += gy[i][j] * xh[i][j];
           dg[i][j] += dv[j] * xh[i][j];
@@ -346,23 +365,54 @@ __global__ __launch_bounds__(64 * ROW_WAVES) void head_bwd_params_kernel(const T
   }
 }
 
-// out[slot][e] = sum_blocks partial[block][slot][e]: 64 columns x 4 block-groups per workgroup, LDS combine in a fixed order
+// out[slot][e] = sum_blocks partial[block][slot][e].  Workgroup = 32 columns (8 lanes x float4) x 32 block-groups: every
+// lane streams 16-byte loads with up to 8 in flight, then the 32 groups are combined through LDS in a fixed order
+// (bitwise reproducible).  D must be a multiple of 4 (the row kernels above require it already).
+#define SR_COLS 32
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ partial, int nblocks, int nslots, int D,
                                                           float* out0, float* out1, float* out2, float* out3, float* out4, int len4) {
-  __shared__ float red[4][64];
-  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + col;
+  __shared__ float4 red[32][8];
+  const int c4 = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  const int e = blockIdx.x * SR_COLS + 4 * c4;
   const int slot = blockIdx.y;
   float* outs[5] = {out0, out1, out2, out3, out4};
   float* o = outs[slot];
   if (!o) return;
   const int len = (slot == 4) ? len4 : D;
-  float s = 0.f;
-  if (e < len)
-    for (int b = grp; b < nblocks; b += 4) s += partial[((size_t)b * nslots + slot) * D + e];
-  red[grp][col] = s;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e < len) {
+    const float* p = partial + (size_t)slot * D + e;
+    const size_t bs = (size_t)nslots * D;
+    int b = grp;
+    for (; b + 32 * 7 < nblocks; b += 32 * 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(b + 32 * u) * bs);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; b < nblocks; b += 32) {
+      const float4 v = *reinterpret_cast<const float4*>(p + (size_t)b * bs);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  red[grp][c4] = s;
   __syncthreads();
-  if (grp == 0 && e < len) o[e] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+  if (grp == 0 && e < len) {
+    float4 t = red[0][c4];
+#pragma unroll
+    for (int gidx = 1; gidx < 32; ++gidx) { const float4 v = red[gidx][c4]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    if (e + 3 < len) *reinterpret_cast<float4*>(o + e) = t;
+    else { const float tv[4] = {t.x, t.y, t.z, t.w}; for (int j = 0; j < 4 && e + j < len; ++j) o[e + j] = tv[j]; }
+  }
+}
+
+// used by band_attn.hip for the fused q/k/v bias gradient
+int mts_slab_reduce_rows(hipStream_t st, const float* partial, int nblocks, int D, float* out) {
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(D, SR_COLS), 1), dim3(256), 0, st, partial, nblocks, 1, D, out, (float*)nullptr,
+                     (float*)nullptr, (float*)nullptr, (float*)nullptr, 0);
+  MTS_LAUNCH_CHECK("slab_reduce");
+  return MTS_OK;
 }
 
 // dpos[pos_offset+i,:] += sum_b dpre[b,i,:]
@@ -373,7 +423,17 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ dp
   if (idx >= (size_t)L * per_row) return;
   const int i = (int)(idx / per_row), e = 4 * (int)(idx % per_row);
   float s[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int b = 0; b < B; ++b) {
+  int b = 0;
+  for (; b + 7 < B; b += 8) {            // 8 documents' loads in flight per lane
+    float v[8][4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) load4<T>(dpre + ((size_t)(b + u) * L + i) * D + e, v[u]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[j] += v[u][j];
+  }
+  for (; b < B; ++b) {
     float v[4];
     load4<T>(dpre + ((size_t)b * L + i) * D + e, v);
 #pragma unroll
@@ -394,6 +454,7 @@ static inline int pick_nv(int D) {
   if (need <= 1) return 1;
   if (need <= 2) return 2;
   if (need <= 4) return 4;
+  if (need == 7) return 7;            // D = 1792, the embedding width of the reference's configs: no idle vector slot
   if (need <= 8) return 8;
   if (need <= 16) return 16;
   return 0;
@@ -404,6 +465,7 @@ template <typename F> static inline void dispatch_nv(int nv, F&& f) {
     case 1: f(std::integral_constant<int, 1>{}); break;
     case 2: f(std::integral_constant<int, 2>{}); break;
     case 4: f(std::integral_constant<int, 4>{}); break;
+    case 7: f(std::integral_constant<int, 7>{}); break;
     case 8: f(std::integral_constant<int, 8>{}); break;
     default: f(std::integral_constant<int, 16>{}); break;
   }
@@ -413,6 +475,7 @@ template <typename F> static inline void dispatch_nv8(int nv, F&& f) {   // kern
     case 1: f(std::integral_constant<int, 1>{}); break;
     case 2: f(std::integral_constant<int, 2>{}); break;
     case 4: f(std::integral_constant<int, 4>{}); break;
+    case 7: f(std::integral_constant<int, 7>{}); break;
     default: f(std::integral_constant<int, 8>{}); break;
   }
 }
@@ -475,7 +538,7 @@ static int ln_bwd_launch(hipStream_t st, int rows, int D, const void* x, const v
     hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), dim3(blocks), dim3(64 * ROW_WAVES), 0, st, (const T*)x, (const T*)dy, dlogit, head_w, n_out, gamma,
                        mean, rstd, rows, D, (T*)dx, (float*)partial);
   });
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(D, 64), 3), dim3(256), 0, st, (const float*)partial, blocks, 3, D, dgamma, dbeta,
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(D, SR_COLS), 3), dim3(256), 0, st, (const float*)partial, blocks, 3, D, dgamma, dbeta,
                      dxsum, (float*)nullptr, (float*)nullptr, 0);
   MTS_LAUNCH_CHECK("layernorm_bwd");
   return MTS_OK;
@@ -541,7 +604,7 @@ extern "C" int mts_head_bwd_params(void* stream, int dtype, int rows, int D, int
   } else { mts_set_error("mts_head_bwd_params: bad dtype %d", dtype); return MTS_ERR_INVALID; }
   float* rowp[4] = {nullptr, nullptr, nullptr, nullptr};
   for (int c = 0; c < n_out; ++c) rowp[c] = dw + (size_t)c * D;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(D, 64), 5), dim3(256), 0, st, (const float*)partial, blocks, 5, D, rowp[0], rowp[1],
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(D, SR_COLS), 5), dim3(256), 0, st, (const float*)partial, blocks, 5, D, rowp[0], rowp[1],
                      rowp[2], rowp[3], db, n_out);
   MTS_LAUNCH_CHECK("mts_head_bwd_params");
   return MTS_OK;

@@ -151,17 +151,21 @@ def band_attn_fwd(qkv, lengths, B, Lq, D, heads, radius, ctx, probs):
         check(lib.mts_band_attn_fwd(stream_ptr(), dtype_code(qkv.dtype), B, Lq, D, heads, radius, ptr(qkv), ptr(lengths), ptr(ctx), ptr(probs)))
 
 
-def band_attn_bwd(qkv, lengths, probs, dctx, B, Lq, D, heads, radius, dqkv, dscores):
+def band_attn_bwd(qkv, lengths, probs, dctx, B, Lq, D, heads, radius, dqkv, dscores, dbias=None):
+    """dbias (fp32 [3D], optional): column sums of dqkv = q/k/v bias gradients, fused into the kernels' output stage."""
     q_scale = 1.0 / math.sqrt(D // heads)
+    ws = _scratch(lib.mts_band_attn_bwd_workspace(B, Lq, D), qkv.device, 'band_bwd') if dbias is not None else None
     with _timed(('band_bwd', B, Lq, D, heads, radius)):
         check(lib.mts_band_attn_bwd(stream_ptr(), dtype_code(qkv.dtype), B, Lq, D, heads, radius, q_scale, ptr(qkv), ptr(lengths),
-                                    ptr(probs), ptr(dctx), ptr(dqkv), ptr(dscores)))
+                                    ptr(probs), ptr(dctx), ptr(dqkv), ptr(dscores), ptr(dbias), ptr(ws)))
 
 
 def tagger_loss(kind, scores, targets, lengths, alpha, gamma, loss_out, dscores):
     B, Lq, n_out = scores.shape
+    nb = lib.mts_tagger_loss_workspace(B, Lq)
+    ws = _scratch(nb, scores.device, 'loss')
     check(lib.mts_tagger_loss(stream_ptr(), kind, B, Lq, targets.shape[1], n_out, ptr(scores), ptr(targets), ptr(lengths),
-                              float(alpha), float(gamma), ptr(loss_out), ptr(dscores)))
+                              float(alpha), float(gamma), ptr(loss_out), ptr(dscores), ptr(ws), nb))
 
 
 def greedy_decode(scores, lengths, threshold, tags_out):

@@ -364,10 +364,9 @@ class Transformer_segmenter(_TaggerBase):
             ops.linear_dgrad(ds1, self._w(wf, lp + 'attention.output.dense.weight'), dctx)
             dqkv = ws.get('dqkv', N, 3 * D, dt, dev)
             dsc = ws.get('dsc', N, H * S['slots'], torch.float32, dev)
-            ops.band_attn_bwd(S['qkv'], st['lengths'], S['probs'], dctx, B, Lq, D, H, S['radius'], dqkv, dsc)
             a_ = lp + 'attention.self.'
             off, n = lay.span(a_ + 'query.bias', a_ + 'value.bias')
-            ops.colsum(dqkv, g[off:off + n])
+            ops.band_attn_bwd(S['qkv'], st['lengths'], S['probs'], dctx, B, Lq, D, H, S['radius'], dqkv, dsc, dbias=g[off:off + n])
             off, n = lay.span(a_ + 'query.weight', a_ + 'value.weight')
             ops.linear_wgrad(dqkv, S['hin'], g[off:off + n].view(3 * D, D))
             self._grads_ready(off, lay.entries[lp + 'attention.output.dense.weight'][0])    # q/k/v weights + biases

@@ -63,6 +63,21 @@ class NativeTrainer:
             return [(off + 2 * D, off + (self._last_L + 2) * D), (end, n)] if off == 0 else [(0, n)]
         return [(0, n)]
 
+    def _adam_spans(self):
+        """Adam without weight decay leaves a parameter whose gradient and both moments are exactly 0 untouched, so the
+        rows of the position table above the longest batch seen so far (never read, gradient always 0) are skipped:
+        bitwise the same result as stepping the whole buffer, a third less optimizer traffic at max_position 4096."""
+        m = self.model
+        n = m.flat.numel()
+        pos = 'model.model.embeddings.position_embeddings.weight'
+        if pos not in m._layout.entries or getattr(self, '_last_L', None) is None:
+            return [(0, n)]
+        off, shape = m._layout.entries[pos]
+        D = shape[1]
+        self._pos_rows = max(getattr(self, '_pos_rows', 0), min(self._last_L + 2, shape[0]))
+        lo, hi = off + self._pos_rows * D, off + shape[0] * D
+        return [(a, b) for a, b in ((0, lo), (hi, n)) if b > a]
+
     def allreduce_grads(self):
         """Blocking exchange of every span (models without gradient-ready hooks, e.g. the recurrent taggers)."""
         if self.world == 1:
@@ -110,7 +125,10 @@ class NativeTrainer:
             ops.sgd_step(m.flat, m.grad_flat(), buf, self.lr, 0.9, 1e-4, self.step_count == 1, gscale, mirror)
         else:
             mm, vv = self._state()
-            ops.adam_step(m.flat, m.grad_flat(), mm, vv, self.lr, 0.9, 0.999, 1e-7, self.step_count, gscale, mirror)
+            g = m.grad_flat()
+            for a, b in self._adam_spans():
+                ops.adam_step(m.flat[a:b], g[a:b], mm[a:b], vv[a:b], self.lr, 0.9, 0.999, 1e-7, self.step_count, gscale,
+                              mirror[a:b] if mirror is not None else None)
         # the kernel wrote `flat` through a raw pointer, which does not bump torch's version counter: keep the
         # bf16-mirror cache of the model coherent by hand
         if mirror is not None:

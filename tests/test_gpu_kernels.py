@@ -85,6 +85,37 @@ def test_gemm_bf16_tile_variants(ops, tile, layout, M, N, K):
         L.check(L.lib.mts_set_option(b'gemm_tile', 0))
 
 
+@pytest.mark.parametrize('layout', ['NT', 'NN', 'TN'])
+@pytest.mark.parametrize('M,N,K', [(512, 448, 1024), (304, 224, 640), (520, 1792, 256)])
+def test_gemm_bf16_tile_224(ops, layout, M, N, K):
+    """256x224 MFMA kernel (N a multiple of 224 = the d=1792 projections), M tails, bias + residual epilogue."""
+    from multimodaltopicsegmentation_amd import _lib as L
+    a = _rnd(M, K, seed=53).to(torch.bfloat16)
+    b = _rnd(N, K, seed=54).to(torch.bfloat16)
+    bias = _rnd(N, seed=55)
+    res = _rnd(M, N, seed=56).to(torch.bfloat16)
+    ref = a.double() @ b.double().t()
+    if layout == 'NT':
+        A, Bm, code = a, b, L.NT
+    elif layout == 'NN':
+        A, Bm, code = a, b.t().contiguous(), L.NN
+    else:
+        A, Bm, code = a.t().contiguous(), b.t().contiguous(), L.TN
+    try:
+        L.check(L.lib.mts_set_option(b'gemm_tile', 224))
+        for out_dtype in ([torch.float32] if layout == 'TN' else [torch.bfloat16, torch.float32]):
+            out = torch.full((M, N), float('nan'), dtype=out_dtype, device=DEV)
+            ops.gemm(code, A.to(DEV), Bm.to(DEV), out, M=M, N=N, K=K)
+            tol = (1e-4, 1e-4 * math.sqrt(K)) if out_dtype == torch.float32 else (1e-2, 2e-2 * math.sqrt(K) / 8)
+            _close(out, ref, tol[0], tol[1], f'{layout} tile 224 {out_dtype}')
+        if layout != 'TN':
+            out = torch.full((M, N), float('nan'), dtype=torch.bfloat16, device=DEV)
+            ops.gemm(code, A.to(DEV), Bm.to(DEV), out, M=M, N=N, K=K, bias=bias.to(DEV), residual=res.to(DEV))
+            _close(out, ref + bias.double() + res.double(), 1e-2, 2e-2 * math.sqrt(K) / 8, f'{layout} tile 224 bias+residual')
+    finally:
+        L.check(L.lib.mts_set_option(b'gemm_tile', 0))
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_gemm_epilogues(ops, dtype):
     M, N, K = 192, 256, 128
@@ -269,7 +300,10 @@ def test_band_attention_fwd_bwd(ops, dtype, B, Lq, D, heads, radius, lengths):
     # backward
     dqkv = torch.full((B * Lq, 3 * D), float('nan'), dtype=dtype, device=DEV)
     dsc = torch.empty_like(probs)
-    ops.band_attn_bwd(qd, li32, probs, dctx.to(DEV), B, Lq, D, heads, radius, dqkv, dsc)
+    dbias = torch.full((3 * D,), float('nan'), device=DEV)
+    ops.band_attn_bwd(qd, li32, probs, dctx.to(DEV), B, Lq, D, heads, radius, dqkv, dsc, dbias=dbias)
+    # fused q/k/v bias gradient = column sums of dqkv exactly as stored
+    _close(dbias, dqkv.cpu().double().sum(0), rtol=1e-5, atol=1e-5 * B * Lq, msg='dbias')
     ref.backward(dctx.double().view(B, Lq, heads, hd))
     scale = 1.0 / math.sqrt(hd)
     got = dqkv.cpu().double().view(B, Lq, 3, heads, hd)
