@@ -144,6 +144,25 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
     }
   };
 
+  // staged bf16 epilogue (see below): its residual chunks are fetched NOW so that they arrive under the K loop
+  bool vec_ok = false;
+  uint4 rres[4][2];
+  if constexpr (sizeof(TC) == 2) {
+    vec_ok = !a.slab && (a.N % 8 == 0) && (a.ldc % 8 == 0) && (((uintptr_t)a.C & 15) == 0) &&
+             (!(a.epi & MTS_EPI_RESIDUAL) || ((a.ldr % 8 == 0) && (((uintptr_t)a.residual & 15) == 0))) &&
+             (!a.aux || ((a.ldaux % 8 == 0) && (((uintptr_t)a.aux & 15) == 0)));
+    if (vec_ok && (a.epi & MTS_EPI_RESIDUAL) && blockIdx.z == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int idx = h * 64 + lane, row = idx >> 3, ch = idx & 7;
+          const int m = min(bm0 + wm * 64 + i * 16 + row, a.M - 1), n = min(bn0 + wn * 64 + ch * 8, a.N - 8);
+          rres[i][h] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.residual) + (size_t)m * a.ldr + n);
+        }
+    }
+  }
+
   if (nk > 0) {
     if constexpr (GLDS) {
       dma_tile(0, 0);
@@ -188,6 +207,39 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
   }
 
   const bool first_slice = (blockIdx.z == 0);
+  if constexpr (sizeof(TC) == 2) {
+    // bf16 output: the accumulator layout gives every lane 4 columns of one row (8-byte pieces of 16 different rows per
+    // instruction).  Stage the wave's 64x64 fp32 sub-tile through LDS 16 rows at a time (the K loop's buffers are free
+    // after its last barrier) and run the epilogue on 8-column chunks of contiguous rows instead: bias / residual / aux /
+    // C move as 16-byte pieces of 128-byte row segments, still one rounding from the fp32 accumulator.
+    if (vec_ok) {
+      constexpr int RS = 64 * 4 + 16;                       // fp32 row of 64 columns + 16 B padding
+      char* stage = smem + wave * (16 * RS);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<float4*>(stage + r16 * RS + (j * 16 + 4 * g) * 4) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int idx = h * 64 + lane, row = idx >> 3, ch = idx & 7;
+          const float4 lo = *reinterpret_cast<const float4*>(stage + row * RS + ch * 32);
+          const float4 hi = *reinterpret_cast<const float4*>(stage + row * RS + ch * 32 + 16);
+          float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          const int m = bm0 + wm * 64 + i * 16 + row, n = bn0 + wn * 64 + ch * 8;
+          if (m < a.M && n < a.N) {
+            epi_math8(a, m, n, v, first_slice, rres[i][h]);
+            uint4 pk;
+            pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + (size_t)m * a.ldc + n) = pk;
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = bm0 + wm * 64 + i * 16 + r16;
@@ -394,6 +446,7 @@ int mts_launch_gemm224(const GemmArgs& a, int layout, bool c_is_f32, int splits,
 static int g_gemm_glds = -1;
 static int g_tile_mode = -1;
 static int g_force_splits = 0;
+static int g_tile_order = 1;
 
 void mts_band_set_mfma(int on);   // band_attn.hip
 extern "C" int mts_set_option(const char* key, int value) {
@@ -401,6 +454,7 @@ extern "C" int mts_set_option(const char* key, int value) {
   if (!strcmp(key, "gemm_tile")) { g_tile_mode = value; return MTS_OK; }
   if (!strcmp(key, "gemm_glds")) { g_gemm_glds = value; return MTS_OK; }
   if (!strcmp(key, "gemm_splits")) { g_force_splits = value; return MTS_OK; }
+  if (!strcmp(key, "gemm_order")) { g_tile_order = value; return MTS_OK; }
   if (!strcmp(key, "band_mfma")) { mts_band_set_mfma(value); return MTS_OK; }
   mts_set_error("mts_set_option: unknown key %s", key);
   return MTS_ERR_INVALID;
@@ -435,7 +489,7 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.residual = residual; a.aux = aux;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.ldaux = ldaux;
   a.epi = epilogue; a.colscale = colscale; a.ncols_scaled = ncols_scaled;
-  a.ksplit = K; a.slab = nullptr;
+  a.ksplit = K; a.slab = nullptr; a.order = g_tile_order;
 
   if (a_dtype == MTS_F32) {
     StrideArgs s;

@@ -116,11 +116,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a)
   const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(a.A);
   const bf16_t* __restrict__ B = reinterpret_cast<const bf16_t*>(a.B);
 
+  // Tile order.  Workgroups b, b+8, b+16.. run on one XCD (round-robin dispatch) and each XCD has its own 4-MiB L2, so an
+  // XCD gets a contiguous run of tile ids, and ids walk the tile grid in bands of 4 tile-rows, column-major inside a band:
+  // the 32 tiles an XCD works on at a time form a 4 x 8 block (4 A panels + 8 B panels per K-step) instead of a
+  // 1.3 x 24 strip that streams ALL of the weight matrix through every L2 in every round.
   auto tile_origin = [&](int t, int& bm0, int& bn0) {
     const int q = nt >> 3, rr = nt & 7, xcd = t & 7, idx = t >> 3;
     const int id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
-    bm0 = (id / ntn) * 256;
-    bn0 = (id % ntn) * BN224;
+    if (a.order == 0) { bm0 = (id / ntn) * 256; bn0 = (id % ntn) * BN224; return; }
+    const int band = id / (4 * ntn), within = id - band * 4 * ntn;
+    const int rows = min(4, ntm - band * 4);
+    bm0 = (band * 4 + within % rows) * 256;
+    bn0 = (within / rows) * BN224;
   };
   int bm0, bn0;
   auto dmaA = [&](int h, int kt) {

@@ -13,6 +13,7 @@ struct GemmArgs {
   unsigned epi;
   float colscale; int ncols_scaled;
   int ksplit;      // K elements per blockIdx.z slice (multiple of 64)
+  int order;       // tile order of the persistent kernels: 1 = 4-row bands (L2-blocked), 0 = row-major
   float* slab;     // split-K: slice z stores its fp32 partial tile to slab[z][M][N] (plain stores); reduced afterwards
 };
 
@@ -41,6 +42,33 @@ __device__ __forceinline__ void epi_math4(const GemmArgs& a, int m, int n, float
     if (a.aux) store4<TA>(reinterpret_cast<TA*>(a.aux) + (size_t)m * a.ldaux + n, v);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = gelu_erf_f(v[i]);
+  }
+}
+
+// the same arithmetic on 8 consecutive in-range columns of row m (bf16 activations): 16-byte aux accesses; r = the residual
+// chunk of (m, n), fetched by the caller ahead of the K loop
+__device__ __forceinline__ void epi_math8(const GemmArgs& a, int m, int n, float (&v)[8], bool first_slice, const uint4& r) {
+  const unsigned epi = a.epi;
+  if ((epi & MTS_EPI_BIAS) && first_slice) {
+    const float4 b0 = *reinterpret_cast<const float4*>(a.bias + n), b1 = *reinterpret_cast<const float4*>(a.bias + n + 4);
+    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+  }
+  if (epi & MTS_EPI_COLSCALE) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (n + i < a.ncols_scaled) v[i] *= a.colscale;
+  }
+  if ((epi & MTS_EPI_RESIDUAL) && first_slice) {
+    v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
+    v[4] += bf16_lo(r.z); v[5] += bf16_hi(r.z); v[6] += bf16_lo(r.w); v[7] += bf16_hi(r.w);
+  }
+  if (epi & MTS_EPI_GELU) {
+    if (a.aux) {
+      uint4 pk;
+      pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
+      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.aux) + (size_t)m * a.ldaux + n) = pk;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = gelu_erf_f(v[i]);
   }
 }
 
