@@ -183,29 +183,44 @@ def main():
         if mflop:
             out['model_tflops'] = value * mflop / 1e6
             out['model_mfma_frac'] = out['model_tflops'] / (MFMA_BF16_PEAK_TFLOPS * world)
-        # roofline of the dominant kernel (by total time): one GEMM symbol = one (layout, output dtype) instantiation
-        names = {0: 'gemm_bf16_kernel<NT,bf16> (forward projections)', 1: 'gemm_bf16_kernel<NN,bf16> (data gradients)',
-                 2: 'gemm_bf16_kernel<TN,f32> (weight gradients)'}
+        # roofline of the dominant kernel (by total time).  One GEMM symbol = one (layout, output dtype, tile) instantiation;
+        # the timed region of a weight-gradient call also holds its split-K reduce kernel (named in the label).
+        sym = {(0, 128): 'gemm_bf16_kernel<NT,bf16,GLDS> (128x128)', (1, 128): 'gemm_bf16_kernel<NN,bf16,GLDS> (128x128)',
+               (2, 128): 'gemm_bf16_kernel<TN,f32,GLDS> (128x128) + splitk_reduce_kernel',
+               (0, 224): 'gemm_bf16_224_kernel<NT,bf16> (256x224)', (1, 224): 'gemm_bf16_224_kernel<NN,bf16> (256x224)',
+               (2, 224): 'gemm_bf16_224_kernel<TN,f32> (256x224) + splitk_reduce_kernel',
+               (0, 256): 'gemm_bf16_256_kernel<NT,bf16> (256x256)', (1, 256): 'gemm_bf16_256_kernel<NN,bf16> (256x256)',
+               (2, 256): 'gemm_bf16_256_kernel<TN,f32> (256x256) + splitk_reduce_kernel'}
+        rocprof_names = {(0, 128): ['void gemm_bf16_kernel<0, bool _Accum, bool, E>(GemmArgs)'], (1, 128): ['void gemm_bf16_kernel<1, bool _Accum, bool, E>(GemmArgs)'],
+                         (2, 128): ['void gemm_bf16_kernel<2, float, true>(GemmArgs)', 'splitk_reduce_kernel(float const*, int, int, int, float*, int, int)'],
+                         (0, 224): ['_Z20gemm_bf16_224_kernelILi0EDF16bEv8GemmArgs'], (1, 224): ['_Z20gemm_bf16_224_kernelILi1EDF16bEv8GemmArgs']}
         per_sym = {}
         other = {}
         for tag, (n, ms) in ksum.items():
             if tag[0] == 'gemm':
-                _, layout, a_dt, c_dt, M, N, K = tag
-                d = per_sym.setdefault((layout, c_dt), {'launches': 0, 'ms': 0.0, 'flop': 0.0})
+                _, layout, a_dt, c_dt, M, N, K, tile = tag
+                d = per_sym.setdefault((layout, tile), {'launches': 0, 'ms': 0.0, 'flop': 0.0})
                 d['launches'] += n
                 d['ms'] += ms
                 d['flop'] += n * 2.0 * M * N * K
             else:
                 other[tag[0]] = {'launches': n, 'avg_us': 1e3 * ms / n}
         if per_sym:
-            (layout, c_dt), dom = max(per_sym.items(), key=lambda kv: kv[1]['ms'])
+            key, dom = max(per_sym.items(), key=lambda kv: kv[1]['ms'])
             ach = dom['flop'] / (dom['ms'] * 1e-3) / 1e12
-            out['roofline'] = {'bound': 'mfma', 'kernel': names.get(layout, str(layout)), 'achieved': ach, 'peak': MFMA_BF16_PEAK_TFLOPS,
-                               'unit': 'TFLOP/s', 'frac': ach / MFMA_BF16_PEAK_TFLOPS, 'traffic': None,
+            # HBM-side bytes per launch from the committed PMC passes (profiles/: FETCH_SIZE x2 + WRITE_SIZE, see tools/pmc_traffic.py)
+            traffic = None
+            try:
+                pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')))
+                traffic = sum(pmc[k]['bytes_per_launch'] for k in rocprof_names.get(key, []) if k in pmc) or None
+            except (OSError, ValueError, KeyError):
+                pass
+            out['roofline'] = {'bound': 'mfma', 'kernel': sym.get(key, str(key)), 'achieved': ach, 'peak': MFMA_BF16_PEAK_TFLOPS,
+                               'unit': 'TFLOP/s', 'frac': ach / MFMA_BF16_PEAK_TFLOPS, 'traffic': traffic,
                                'launches_timed': dom['launches'], 'avg_launch_us': 1e3 * dom['ms'] / dom['launches'],
                                'algorithmic_gflop_per_launch': dom['flop'] / dom['launches'] / 1e9}
-            out['kernels'] = {names.get(l, str(l)): {'launches': d['launches'], 'avg_us': 1e3 * d['ms'] / d['launches'],
-                                                     'tflops': d['flop'] / (d['ms'] * 1e-3) / 1e12} for (l, c), d in per_sym.items()}
+            out['kernels'] = {sym.get(k, str(k)): {'launches': d['launches'], 'avg_us': 1e3 * d['ms'] / d['launches'],
+                                                    'tflops': d['flop'] / (d['ms'] * 1e-3) / 1e12} for k, d in per_sym.items()}
             # the HBM-bound headline kernel: band attention, 14 336 algorithmic bytes per sentence (bf16 q,k,v in, ctx out)
             if 'band_fwd' in other:
                 by = args.docs * args.seq * 4 * D * (2 if args.dtype == 'bf16' else 4)

@@ -44,8 +44,10 @@ typedef enum { MTS_LOSS_CE = 0, MTS_LOSS_BCE = 1, MTS_LOSS_FOCAL = 2 } mts_loss_
 /* GEMM operand layouts.  C[M,N] = op(A) * op(B):
  *   MTS_NT : A is [M,K] (K contiguous), B is [N,K] (K contiguous)   -- y = x W^T        (forward)
  *   MTS_NN : A is [M,K] (K contiguous), B is [K,N] (N contiguous)   -- dx = dy W        (data grad)
- *   MTS_TN : A is [K,M] (M contiguous), B is [K,N] (N contiguous)   -- dW = dy^T x      (weight grad)   */
-typedef enum { MTS_NT = 0, MTS_NN = 1, MTS_TN = 2 } mts_gemm_layout;
+ *   MTS_TN : A is [K,M] (M contiguous), B is [K,N] (N contiguous)   -- dW = dy^T x      (weight grad)
+ *   MTS_TT : A is [K,M] (M contiguous), B is [N,K] (K contiguous)   -- dW = dy^T (x^T)^T with x^T materialised by
+ *            mts_transpose: one operand less goes through the transposing LDS reads (weight grad of the wide projections) */
+typedef enum { MTS_NT = 0, MTS_NN = 1, MTS_TN = 2, MTS_TT = 3 } mts_gemm_layout;
 
 /* epilogue flags for mts_gemm */
 #define MTS_EPI_BIAS      1u   /* += bias[n]  (fp32 [N])                                  */
@@ -57,8 +59,11 @@ typedef enum { MTS_NT = 0, MTS_NN = 1, MTS_TN = 2 } mts_gemm_layout;
 const char* mts_last_error(void);
 /* version / build info: "mts-hip <n> gfx950" */
 const char* mts_version(void);
-/* tuning / A-B switches: "gemm_tile" = 0 (cost model) | 128 | 256 ; "gemm_glds" = 1 (LDS-DMA staging) | 0 (register staging) */
+/* tuning / A-B switches: "gemm_tile" = 0 (cost model) | 128 | 224 | 256 ; "gemm_glds" = 1 (LDS-DMA staging) | 0 (register
+ * staging) ; "gemm_splits" = 0 (cost model) | n ; "gemm_order" = 1 (L2-blocked tile order) | 0 ; "band_mfma" = 1 | 0 */
 int mts_set_option(const char* key, int value);
+/* tile width (128 | 224 | 256) and K split the cost model chose for the most recent bf16 mts_gemm (bench / profiling labels) */
+int mts_gemm_last_plan(int* tile, int* splits);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense projection GEMM (MFMA for bf16, exact-fp32 VALU kernel for parity mode).

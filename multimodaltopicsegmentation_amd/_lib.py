@@ -21,7 +21,7 @@ lib = C.CDLL(LIB_PATH)
 
 F32, BF16 = 0, 1
 LOSS_CE, LOSS_BCE, LOSS_FOCAL = 0, 1, 2
-NT, NN, TN = 0, 1, 2
+NT, NN, TN, TT = 0, 1, 2, 3
 EPI_BIAS, EPI_RESIDUAL, EPI_GELU, EPI_COLSCALE, EPI_ACCUM = 1, 2, 4, 8, 16
 
 _vp, _i, _f, _u, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint, C.c_size_t
@@ -31,6 +31,7 @@ SIGNATURES = {
     'mts_last_error': (C.c_char_p, []),
     'mts_version': (C.c_char_p, []),
     'mts_set_option': (_i, [C.c_char_p, _i]),
+    'mts_gemm_last_plan': (_i, [_vp, _vp]),
     'mts_gemm': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _u, _f, _i, _vp, _sz]),
     'mts_colsum_workspace': (_sz, [_i]),
     'mts_colsum': (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _vp]),

@@ -16,7 +16,141 @@ __device__ __forceinline__ float lse_arr(const float* v, int n) {
   return m + logf(s);
 }
 
-// one thread per document (C^2 = 16 flops per step: latency-bound on the dependent chain, not on lanes)
+
+// ------------------------------------------------------------------------------------------------
+// C == 4 (binary tagset + START/STOP: every configuration of the reference): one QUAD of lanes per document, lane i
+// owns tag i.  The C x C table lives in 8 registers per lane (its row and its column), the alpha/beta vectors are
+// exchanged with DPP quad broadcasts, so a step is ~4 exp + 1 log per lane with no memory on the dependent chain except the
+// (prefetchable) emission row.  Same association of the additions as the generic kernel below.
+// ------------------------------------------------------------------------------------------------
+template <int J> __device__ __forceinline__ float quad_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), J * 0x55, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lse4(float v0, float v1, float v2, float v3) {
+  const float m = fmaxf(fmaxf(fmaxf(v0, v1), v2), v3);
+  const float s = ((expf(v0 - m) + expf(v1 - m)) + expf(v2 - m)) + expf(v3 - m);
+  return m + logf(s);
+}
+
+__global__ __launch_bounds__(64) void crf_nll4_kernel(int B, int L, const float* __restrict__ feats, const float* __restrict__ tags, int Lt,
+                                                      const int32_t* __restrict__ lengths, const float* __restrict__ trans,
+                                                      float* __restrict__ dfeats, float* __restrict__ alphas, float* __restrict__ part) {
+  constexpr int C = 4, start = 2, stop = 3;
+  const int i = threadIdx.x & 3;
+  const int b = blockIdx.x * 16 + (threadIdx.x >> 2);
+  if (b >= B) return;                                   // whole quads leave together
+  const int n = lengths ? max(min(lengths[b], L), 0) : L;
+  float Tr[4], Tc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { Tr[j] = trans[i * C + j]; Tc[j] = trans[j * C + i]; }
+  const float Tstop = trans[stop * C + i];
+  const float* f = feats + (size_t)b * L * C;
+  float* al = alphas + (size_t)b * (L + 1) * C;
+  const float* tg = tags + (size_t)b * Lt;
+  float a = (i == start) ? 0.f : CRF_IMPOSSIBLE;
+  al[i] = a;
+  float fn = n > 0 ? f[i] : 0.f;
+  for (int t = 0; t < n; ++t) {
+    const float ft = fn;
+    if (t + 1 < n) fn = f[(t + 1) * C + i];              // next emission row in flight behind this step's exp/log
+    const float v0 = quad_bcast<0>(a) + Tr[0] + ft, v1 = quad_bcast<1>(a) + Tr[1] + ft;
+    const float v2 = quad_bcast<2>(a) + Tr[2] + ft, v3 = quad_bcast<3>(a) + Tr[3] + ft;
+    a = lse4(v0, v1, v2, v3);
+    al[(t + 1) * C + i] = a;
+  }
+  const float vs = a + Tstop;
+  const float logZ = lse4(quad_bcast<0>(vs), quad_bcast<1>(vs), quad_bcast<2>(vs), quad_bcast<3>(vs));
+  // gold path score (CRF.py:148-170): the 4 lanes take every 4th step, combined in a fixed order
+  float gpart = 0.f;
+  for (int t = i; t < n; t += 4) {
+    const int y = (int)tg[t], prev = t > 0 ? (int)tg[t - 1] : start;
+    gpart += trans[y * C + prev] + f[t * C + y];
+  }
+  const int last = n > 0 ? (int)tg[n - 1] : start;
+  const float gold = ((quad_bcast<0>(gpart) + quad_bcast<1>(gpart)) + (quad_bcast<2>(gpart) + quad_bcast<3>(gpart))) + trans[stop * C + last];
+  float* pp = part + (size_t)b * (C * C + 1);
+  if (i == 0) pp[C * C] = logZ - gold;
+  if (!dfeats) return;
+  // reverse sweep: beta recursion -> marginals; the gold path's one-hot counts are subtracted on the fly
+  float dT[4] = {0.f, 0.f, 0.f, 0.f};
+  const float dstop = expf(a + Tstop - logZ);            // P(last tag = i): row `stop`, column i
+  float beta = Tstop;
+  float* df = dfeats + (size_t)b * L * C;
+  for (int t = n - 1; t >= 0; --t) {
+    const float ft = f[t * C + i], anext = al[(t + 1) * C + i], aprev = al[t * C + i];
+    const int y = (int)tg[t], prev = t > 0 ? (int)tg[t - 1] : start;
+    float marg = expf(anext + beta - logZ);
+    const float ap0 = quad_bcast<0>(aprev), ap1 = quad_bcast<1>(aprev), ap2 = quad_bcast<2>(aprev), ap3 = quad_bcast<3>(aprev);
+    dT[0] += expf(ap0 + Tr[0] + ft + beta - logZ);
+    dT[1] += expf(ap1 + Tr[1] + ft + beta - logZ);
+    dT[2] += expf(ap2 + Tr[2] + ft + beta - logZ);
+    dT[3] += expf(ap3 + Tr[3] + ft + beta - logZ);
+    if (y == i) {
+      marg -= 1.f;
+      dT[0] -= (prev == 0) ? 1.f : 0.f; dT[1] -= (prev == 1) ? 1.f : 0.f; dT[2] -= (prev == 2) ? 1.f : 0.f; dT[3] -= (prev == 3) ? 1.f : 0.f;
+    }
+    const float nb = lse4(Tc[0] + quad_bcast<0>(ft) + quad_bcast<0>(beta), Tc[1] + quad_bcast<1>(ft) + quad_bcast<1>(beta),
+                          Tc[2] + quad_bcast<2>(ft) + quad_bcast<2>(beta), Tc[3] + quad_bcast<3>(ft) + quad_bcast<3>(beta));
+    df[t * C + i] = marg;
+    beta = nb;
+  }
+  for (int t = n; t < L; ++t) df[t * C + i] = 0.f;
+  const float ds0 = quad_bcast<0>(dstop), ds1 = quad_bcast<1>(dstop), ds2 = quad_bcast<2>(dstop), ds3 = quad_bcast<3>(dstop);
+  if (i == stop) {
+    dT[0] += ds0; dT[1] += ds1; dT[2] += ds2; dT[3] += ds3;
+    dT[0] -= (last == 0) ? 1.f : 0.f; dT[1] -= (last == 1) ? 1.f : 0.f; dT[2] -= (last == 2) ? 1.f : 0.f; dT[3] -= (last == 3) ? 1.f : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) pp[i * C + j] = dT[j];
+}
+
+// Viterbi for C == 4: back-pointers stay in LDS (one byte each), the back-trace is walked by the quad's first lane
+__global__ __launch_bounds__(64) void crf_viterbi4_kernel(int B, int L, const float* __restrict__ feats, const int32_t* __restrict__ lengths,
+                                                          const float* __restrict__ trans, float* __restrict__ best_score, int32_t* __restrict__ paths) {
+  extern __shared__ unsigned char bp_lds[];            // [16 documents][L][4]
+  constexpr int C = 4, start = 2, stop = 3;
+  const int i = threadIdx.x & 3, q = threadIdx.x >> 2;
+  const int b = blockIdx.x * 16 + q;
+  if (b >= B) return;
+  const int n = lengths ? max(min(lengths[b], L), 0) : L;
+  float Tr[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) Tr[j] = trans[i * C + j];
+  const float* f = feats + (size_t)b * L * C;
+  unsigned char* bp = bp_lds + (size_t)q * L * C;
+  float m = (i == start) ? 0.f : CRF_IMPOSSIBLE;
+  float fn = n > 0 ? f[i] : 0.f;
+  for (int t = 0; t < n; ++t) {
+    const float ft = fn;
+    if (t + 1 < n) fn = f[(t + 1) * C + i];
+    float best = quad_bcast<0>(m) + Tr[0];
+    int arg = 0;
+    float v = quad_bcast<1>(m) + Tr[1]; if (v > best) { best = v; arg = 1; }
+    v = quad_bcast<2>(m) + Tr[2]; if (v > best) { best = v; arg = 2; }
+    v = quad_bcast<3>(m) + Tr[3]; if (v > best) { best = v; arg = 3; }
+    bp[t * C + i] = (unsigned char)arg;
+    m = best + ft;
+  }
+  const float vs = m + trans[stop * C + i];
+  float best = quad_bcast<0>(vs);
+  int tag = 0;
+  float v = quad_bcast<1>(vs); if (v > best) { best = v; tag = 1; }
+  v = quad_bcast<2>(vs); if (v > best) { best = v; tag = 2; }
+  v = quad_bcast<3>(vs); if (v > best) { best = v; tag = 3; }
+  int32_t* p = paths + (size_t)b * L;
+  for (int t = n + i; t < L; t += 4) p[t] = -1;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  if (i == 0) {
+    best_score[b] = best;
+    for (int t = n - 1; t >= 0; --t) {
+      p[t] = tag;
+      tag = bp[t * C + tag];
+    }
+  }
+}
+
+// generic C (3..8): one thread per document (C^2 = 16 flops per step: latency-bound on the dependent chain, not on lanes)
 __global__ __launch_bounds__(64) void crf_nll_kernel(int B, int L, int C, const float* __restrict__ feats, const float* __restrict__ tags, int Lt,
                                                      const int32_t* __restrict__ lengths, const float* __restrict__ trans,
                                                      float* __restrict__ dfeats, float* __restrict__ alphas /*[B][L+1][C]*/,
@@ -171,7 +305,8 @@ extern "C" int mts_crf_nll(void* stream, int B, int L, int C, const float* feats
   hipStream_t st = (hipStream_t)stream;
   float* alphas = workspace;
   float* part = workspace + (size_t)B * (L + 1) * C;
-  hipLaunchKernelGGL(crf_nll_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, st, B, L, C, feats, tags, Lt, lengths, trans, dfeats, alphas, part);
+  if (C == 4) hipLaunchKernelGGL(crf_nll4_kernel, dim3(ceil_div(B, 16)), dim3(64), 0, st, B, L, feats, tags, Lt, lengths, trans, dfeats, alphas, part);
+  else hipLaunchKernelGGL(crf_nll_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, st, B, L, C, feats, tags, Lt, lengths, trans, dfeats, alphas, part);
   const int blocks = dfeats ? std::min(256, ceil_div(B * L * C, 256)) : 1;
   hipLaunchKernelGGL(crf_finish_kernel, dim3(blocks), dim3(256), 0, st, B, L, C, (const float*)part, loss_out, dfeats, dtrans);
   MTS_LAUNCH_CHECK("mts_crf_nll");
@@ -182,7 +317,11 @@ extern "C" int mts_crf_viterbi(void* stream, int B, int L, int C, const float* f
                                float* best_score, int32_t* paths, int32_t* bp_ws) {
   MTS_CHECK_ARG(B > 0 && L > 0 && C >= 3 && C <= CRF_MAXC, "mts_crf_viterbi: bad shape (C must be in 3..8)");
   MTS_CHECK_ARG(feats && trans && best_score && paths && bp_ws, "mts_crf_viterbi: null pointer");
-  hipLaunchKernelGGL(crf_viterbi_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, B, L, C, feats, lengths, trans, best_score, paths, bp_ws);
+  if (C == 4 && (size_t)16 * L * 4 <= 64 * 1024)
+    hipLaunchKernelGGL(crf_viterbi4_kernel, dim3(ceil_div(B, 16)), dim3(64), (size_t)16 * L * 4, (hipStream_t)stream, B, L, feats, lengths, trans, best_score,
+                       paths);
+  else
+    hipLaunchKernelGGL(crf_viterbi_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, B, L, C, feats, lengths, trans, best_score, paths, bp_ws);
   MTS_LAUNCH_CHECK("mts_crf_viterbi");
   return MTS_OK;
 }

@@ -29,8 +29,8 @@
 // rows/columns past M/N are clamped to valid memory (they only feed outputs that are never stored).
 template <int LAYOUT, typename TC, bool GLDS>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
-  constexpr bool A_KMAJOR = (LAYOUT != MTS_TN);
-  constexpr bool B_KMAJOR = (LAYOUT == MTS_NT);
+  constexpr bool A_KMAJOR = (LAYOUT == MTS_NT || LAYOUT == MTS_NN);
+  constexpr bool B_KMAJOR = (LAYOUT == MTS_NT || LAYOUT == MTS_TT);
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A stage | B stage]
 
   const int tid = threadIdx.x;
@@ -447,6 +447,13 @@ static int g_gemm_glds = -1;
 static int g_tile_mode = -1;
 static int g_force_splits = 0;
 static int g_tile_order = 1;
+static int g_last_tile = 0, g_last_splits = 0;   // what the planner chose for the most recent bf16 mts_gemm (bench.py labels)
+
+extern "C" int mts_gemm_last_plan(int* tile, int* splits) {
+  if (tile) *tile = g_last_tile;
+  if (splits) *splits = g_last_splits;
+  return MTS_OK;
+}
 
 void mts_band_set_mfma(int on);   // band_attn.hip
 extern "C" int mts_set_option(const char* key, int value) {
@@ -478,7 +485,7 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
                         void* aux, int ldaux, unsigned epilogue, float colscale, int ncols_scaled, void* workspace, size_t workspace_bytes) {
   MTS_CHECK_ARG(M > 0 && N > 0 && K > 0, "mts_gemm: bad shape M=%d N=%d K=%d", M, N, K);
   MTS_CHECK_ARG(A && B && C, "mts_gemm: null operand");
-  MTS_CHECK_ARG(layout == MTS_NT || layout == MTS_NN || layout == MTS_TN, "mts_gemm: bad layout %d", layout);
+  MTS_CHECK_ARG(layout == MTS_NT || layout == MTS_NN || layout == MTS_TN || layout == MTS_TT, "mts_gemm: bad layout %d", layout);
   MTS_CHECK_ARG(a_dtype == MTS_F32 || a_dtype == MTS_BF16, "mts_gemm: bad a_dtype %d", a_dtype);
   MTS_CHECK_ARG(c_dtype == MTS_F32 || c_dtype == a_dtype, "mts_gemm: c_dtype must be f32 or a_dtype");
   MTS_CHECK_ARG(!(epilogue & MTS_EPI_BIAS) || bias, "mts_gemm: MTS_EPI_BIAS without bias");
@@ -495,6 +502,7 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
     StrideArgs s;
     if (layout == MTS_NT) { s.sam = lda; s.sak = 1; s.sbn = ldb; s.sbk = 1; }
     else if (layout == MTS_NN) { s.sam = lda; s.sak = 1; s.sbn = 1; s.sbk = ldb; }
+    else if (layout == MTS_TT) { s.sam = 1; s.sak = lda; s.sbn = ldb; s.sbk = 1; }
     else { s.sam = 1; s.sak = lda; s.sbn = 1; s.sbk = ldb; }
     MTS_CHECK_ARG(ldc % 4 == 0 && ((uintptr_t)C % 16) == 0, "mts_gemm(f32): C must be 16-byte aligned with ldc %% 4 == 0");
     MTS_CHECK_ARG(!(epilogue & MTS_EPI_RESIDUAL) || (ldr % 4 == 0), "mts_gemm(f32): ldr %% 4");
@@ -509,6 +517,7 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
   if (layout == MTS_NT) MTS_UNSUPPORTED(K % 8 == 0, "mts_gemm(bf16,NT): K %% 8 != 0 (K=%d)", K);
   if (layout == MTS_NN) MTS_UNSUPPORTED(K % 8 == 0 && N % 8 == 0, "mts_gemm(bf16,NN): K,N %% 8 (K=%d N=%d)", K, N);
   if (layout == MTS_TN) MTS_UNSUPPORTED(M % 8 == 0 && N % 8 == 0, "mts_gemm(bf16,TN): M,N %% 8 (M=%d N=%d)", M, N);
+  if (layout == MTS_TT) MTS_UNSUPPORTED(M % 8 == 0 && K % 8 == 0, "mts_gemm(bf16,TT): M,K %% 8 (M=%d K=%d)", M, K);
   MTS_UNSUPPORTED(ldc % 4 == 0 && ((uintptr_t)C % (c_dtype == MTS_F32 ? 16 : 8)) == 0, "mts_gemm(bf16): C alignment/ldc");
   MTS_UNSUPPORTED(!(epilogue & MTS_EPI_RESIDUAL) || (ldr % 4 == 0 && ((uintptr_t)residual % 8) == 0), "mts_gemm(bf16): residual alignment");
   MTS_UNSUPPORTED(!aux || (ldaux % 4 == 0 && ((uintptr_t)aux % 8) == 0), "mts_gemm(bf16): aux alignment");
@@ -525,7 +534,7 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
   const unsigned plain = epilogue & ~MTS_EPI_ACCUM;
   const bool can_split = (c_dtype == MTS_F32 && plain == 0 && workspace && N % 4 == 0 && K >= 2048);
   // 256-tile kernel: K-contiguous A only (its transposed-read TN form measures slower than the 128 kernel)
-  const bool can256 = (K % BK == 0) && K >= 512 && M >= 8 && N >= 8 && tile_mode != 128 && (layout != MTS_TN || tile_mode == 256);
+  const bool can256 = (K % BK == 0) && K >= 512 && M >= 8 && N >= 8 && tile_mode != 128 && (layout != MTS_TN || tile_mode >= 224);
   const double bw = 3500.0;     // slab MB per us
   double best = 1e30;
   int splits = 1;
@@ -551,6 +560,8 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
       if (cost < best) { best = cost; splits = sp; use256 = big; }
     }
   }
+  g_last_tile = use256 == 2 ? 224 : use256 == 1 ? 256 : 128;
+  g_last_splits = splits;
   a.slab = nullptr;
   if (splits > 1) {
     a.ksplit = ceil_div(ceil_div(K, splits), BK) * BK;
@@ -562,10 +573,12 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
   } else if (c_dtype == MTS_F32) {
     if (layout == MTS_NT) launch_bf16<MTS_NT, float>(a, splits, st);
     else if (layout == MTS_NN) launch_bf16<MTS_NN, float>(a, splits, st);
+    else if (layout == MTS_TT) launch_bf16<MTS_TT, float>(a, splits, st);
     else launch_bf16<MTS_TN, float>(a, splits, st);
   } else {
     if (layout == MTS_NT) launch_bf16<MTS_NT, bf16_t>(a, splits, st);
     else if (layout == MTS_NN) launch_bf16<MTS_NN, bf16_t>(a, splits, st);
+    else if (layout == MTS_TT) launch_bf16<MTS_TT, bf16_t>(a, splits, st);
     else launch_bf16<MTS_TN, bf16_t>(a, splits, st);
   }
   if (splits > 1)

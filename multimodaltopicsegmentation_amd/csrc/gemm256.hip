@@ -100,8 +100,8 @@ __device__ __forceinline__ void store_tile_256(const GemmArgs& a, f32x4 (&acc)[8
 
 template <int LAYOUT, typename TC>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GemmArgs a) {
-  constexpr bool A_KMAJOR = (LAYOUT != MTS_TN);
-  constexpr bool B_KMAJOR = (LAYOUT == MTS_NT);
+  constexpr bool A_KMAJOR = (LAYOUT == MTS_NT || LAYOUT == MTS_NN);
+  constexpr bool B_KMAJOR = (LAYOUT == MTS_NT || LAYOUT == MTS_TT);
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A0 | A1 | B0 | B1] + 8 x 4 KiB store staging
 
   const int tid = threadIdx.x;
@@ -281,9 +281,11 @@ int mts_launch_gemm256(const GemmArgs& a, int layout, bool c_is_f32, int splits,
   if (c_is_f32) {
     if (layout == MTS_NT) return launch_one<MTS_NT, float>(a, splits, st);
     if (layout == MTS_NN) return launch_one<MTS_NN, float>(a, splits, st);
+    if (layout == MTS_TT) return launch_one<MTS_TT, float>(a, splits, st);
     return launch_one<MTS_TN, float>(a, splits, st);
   }
   if (layout == MTS_NT) return launch_one<MTS_NT, bf16_t>(a, splits, st);
   if (layout == MTS_NN) return launch_one<MTS_NN, bf16_t>(a, splits, st);
+  if (layout == MTS_TT) return launch_one<MTS_TT, bf16_t>(a, splits, st);
   return launch_one<MTS_TN, bf16_t>(a, splits, st);
 }

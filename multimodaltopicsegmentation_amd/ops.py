@@ -1,6 +1,7 @@
 """Tensor-level wrappers over the C ABI (include/mts.h).  torch is used for device memory and streams only:
 every function enqueues hand-written HIP kernels on torch's current stream through raw device pointers.
 """
+import ctypes
 import math
 
 import torch
@@ -53,6 +54,9 @@ def _scratch(nbytes, device, tag):
     return buf
 
 
+_plan_cache = {}
+
+
 def gemm(layout, A, B, out, *, M, N, K, lda=None, ldb=None, ldc=None, bias=None, residual=None, aux=None, gelu=False,
          colscale=None, ncols_scaled=0, accumulate=False):
     """C[M,N] = op(A) op(B) (+ epilogue).  A/B share a dtype (fp32 or bf16); out is fp32 or that dtype."""
@@ -74,14 +78,19 @@ def gemm(layout, A, B, out, *, M, N, K, lda=None, ldb=None, ldc=None, bias=None,
     ldb = ldb if ldb is not None else B.stride(0)
     ldc = ldc if ldc is not None else out.stride(0)
     ws, ws_bytes = None, 0
-    if layout == L.TN and c_dt == L.F32 and a_dt == L.BF16 and K >= 2048:
+    if layout in (L.TN, L.TT) and c_dt == L.F32 and a_dt == L.BF16 and K >= 2048:
         ws_bytes = min(16, max(1, K // 1024)) * M * N * 4          # room for up to 16 split-K partial planes
         ws = _scratch(ws_bytes, A.device, 'splitk')
-    with _timed(('gemm', layout, a_dt, c_dt, M, N, K)):
+    key = (layout, a_dt, c_dt, M, N, K)
+    with _timed(('gemm', *key, _plan_cache.get(key, 0))):
         check(lib.mts_gemm(stream_ptr(), a_dt, c_dt, layout, M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc, ptr(bias),
                            ptr(residual), residual.stride(0) if residual is not None else 0, ptr(aux),
                            aux.stride(0) if aux is not None else 0, epi, float(colscale or 1.0), int(ncols_scaled),
                            ptr(ws), ws_bytes))
+    if a_dt == L.BF16 and key not in _plan_cache:       # which kernel the cost model picked (128 | 224 | 256): timer label
+        t = ctypes.c_int(0)
+        lib.mts_gemm_last_plan(ctypes.byref(t), None)
+        _plan_cache[key] = t.value
     return out
 
 

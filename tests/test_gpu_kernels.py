@@ -85,7 +85,7 @@ def test_gemm_bf16_tile_variants(ops, tile, layout, M, N, K):
         L.check(L.lib.mts_set_option(b'gemm_tile', 0))
 
 
-@pytest.mark.parametrize('layout', ['NT', 'NN', 'TN'])
+@pytest.mark.parametrize('layout', ['NT', 'NN', 'TN', 'TT'])
 @pytest.mark.parametrize('M,N,K', [(512, 448, 1024), (304, 224, 640), (520, 1792, 256)])
 def test_gemm_bf16_tile_224(ops, layout, M, N, K):
     """256x224 MFMA kernel (N a multiple of 224 = the d=1792 projections), M tails, bias + residual epilogue."""
@@ -99,16 +99,18 @@ def test_gemm_bf16_tile_224(ops, layout, M, N, K):
         A, Bm, code = a, b, L.NT
     elif layout == 'NN':
         A, Bm, code = a, b.t().contiguous(), L.NN
+    elif layout == 'TT':
+        A, Bm, code = a.t().contiguous(), b, L.TT
     else:
         A, Bm, code = a.t().contiguous(), b.t().contiguous(), L.TN
     try:
         L.check(L.lib.mts_set_option(b'gemm_tile', 224))
-        for out_dtype in ([torch.float32] if layout == 'TN' else [torch.bfloat16, torch.float32]):
+        for out_dtype in ([torch.float32] if layout in ('TN', 'TT') else [torch.bfloat16, torch.float32]):
             out = torch.full((M, N), float('nan'), dtype=out_dtype, device=DEV)
             ops.gemm(code, A.to(DEV), Bm.to(DEV), out, M=M, N=N, K=K)
             tol = (1e-4, 1e-4 * math.sqrt(K)) if out_dtype == torch.float32 else (1e-2, 2e-2 * math.sqrt(K) / 8)
             _close(out, ref, tol[0], tol[1], f'{layout} tile 224 {out_dtype}')
-        if layout != 'TN':
+        if layout not in ('TN', 'TT'):
             out = torch.full((M, N), float('nan'), dtype=torch.bfloat16, device=DEV)
             ops.gemm(code, A.to(DEV), Bm.to(DEV), out, M=M, N=N, K=K, bias=bias.to(DEV), residual=res.to(DEV))
             _close(out, ref + bias.double() + res.double(), 1e-2, 2e-2 * math.sqrt(K) / 8, f'{layout} tile 224 bias+residual')

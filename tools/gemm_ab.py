@@ -11,7 +11,7 @@ from multimodaltopicsegmentation_amd import _lib as L, ops  # noqa: E402
 
 key, vals = sys.argv[1].encode(), [int(v) for v in sys.argv[2:]]
 SHAPES = [('NT', 16384, 5376, 1792), ('NT', 16384, 1792, 1792), ('NN', 16384, 1792, 5376), ('NN', 16384, 1792, 1792),
-          ('TN', 5376, 1792, 16384), ('TN', 1792, 1792, 16384)]
+          ('TN', 5376, 1792, 16384), ('TN', 1792, 1792, 16384), ('TT', 5376, 1792, 16384), ('TT', 1792, 1792, 16384)]
 dev = 'cuda'
 for lay, M, N, K in SHAPES:
     g = torch.Generator(device=dev).manual_seed(1)
@@ -19,11 +19,13 @@ for lay, M, N, K in SHAPES:
         A, B = torch.randn(M, K, device=dev, generator=g), torch.randn(N, K, device=dev, generator=g)
     elif lay == 'NN':
         A, B = torch.randn(M, K, device=dev, generator=g), torch.randn(K, N, device=dev, generator=g)
+    elif lay == 'TT':
+        A, B = torch.randn(K, M, device=dev, generator=g), torch.randn(N, K, device=dev, generator=g)
     else:
         A, B = torch.randn(K, M, device=dev, generator=g), torch.randn(K, N, device=dev, generator=g)
     A, B = A.to(torch.bfloat16), B.to(torch.bfloat16)
-    out = torch.empty(M, N, dtype=torch.float32 if lay == 'TN' else torch.bfloat16, device=dev)
-    code = {'NT': L.NT, 'NN': L.NN, 'TN': L.TN}[lay]
+    out = torch.empty(M, N, dtype=torch.float32 if lay in ('TN', 'TT') else torch.bfloat16, device=dev)
+    code = {'NT': L.NT, 'NN': L.NN, 'TN': L.TN, 'TT': L.TT}[lay]
     res = {v: [] for v in vals}
     for rep in range(3):
         for v in vals:
