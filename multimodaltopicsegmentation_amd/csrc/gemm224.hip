@@ -51,6 +51,21 @@ __device__ __forceinline__ void store_tile_224(const GemmArgs& a, f32x4 (&acc)[4
   const bool vec_ok = (a.N % 8 == 0) && (a.ldc % 8 == 0);
   if constexpr (sizeof(TC) == 2) {
     if (!a.slab && vec_ok) {
+      // all of the tile's residual pieces are requested up front (the MFMA fragments are dead, their registers are free):
+      // one exposed memory latency per tile instead of one per 16-row pass
+      const bool has_res = (a.epi & MTS_EPI_RESIDUAL) && first_slice;
+      uint2 rr[4][7];
+      if (has_res) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = min(m0 + i * 16 + r16, a.M - 1);
+#pragma unroll
+          for (int j = 0; j < 7; ++j)
+            rr[i][j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.residual) + (size_t)m * a.ldr + min(n0 + j * 16 + 4 * g, a.N - 4));
+        }
+      }
+      GemmArgs a2 = a;
+      a2.epi = a.epi & ~MTS_EPI_RESIDUAL;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int m = m0 + i * 16 + r16;
@@ -58,7 +73,15 @@ __device__ __forceinline__ void store_tile_224(const GemmArgs& a, f32x4 (&acc)[4
         for (int j = 0; j < 7; ++j) {
           const int n = n0 + j * 16 + 4 * g;
           float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-          if (m < a.M && n < a.N) epi_math4<bf16_t>(a, m, n, v, first_slice);
+          if (m < a.M && n < a.N) {
+            // same order as epi_math4: bias, column scale, residual, GELU (GELU never comes with a residual in this model)
+            if (has_res && !(a.epi & MTS_EPI_GELU)) {
+              epi_math4<bf16_t>(a2, m, n, v, first_slice);
+              v[0] += bf16_lo(rr[i][j].x); v[1] += bf16_hi(rr[i][j].x); v[2] += bf16_lo(rr[i][j].y); v[3] += bf16_hi(rr[i][j].y);
+            } else {
+              epi_math4<bf16_t>(a, m, n, v, first_slice);
+            }
+          }
           uint2 pk;
           pk.x = pack_bf16x2(v[0], v[1]);
           pk.y = pack_bf16x2(v[2], v[3]);
