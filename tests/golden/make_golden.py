@@ -393,8 +393,75 @@ def g11_boundaries():
     save('g11_boundaries', **out)
 
 
+def g12_loader():
+    """On-disk formats (utils/load_datasets_precomputed.py:103-224): a synthetic corpus written to a temp dir, loaded by the
+    reference with a standard split (+ timing features), without a split (5 folds) and for inference.  The fixture holds the
+    corpus itself (inputs) and, per returned item, its file name, labels and embedding matrix (outputs)."""
+    import json
+    import pickle
+    import tempfile
+    from utils.load_datasets_precomputed import load_dataset_for_inference, load_dataset_from_precomputed
+    rng = np.random.default_rng(1212)
+    names = [f'doc{i:02d}.npy' for i in range(11)]
+    lens = [int(v) for v in rng.integers(3, 12, len(names))]
+    out = {'names': np.array(names), 'lens': np.array(lens)}
+    with tempfile.TemporaryDirectory() as tmp:
+        da, db = os.path.join(tmp, 'text'), os.path.join(tmp, 'audio')
+        os.makedirs(da), os.makedirs(db)
+        labs, times = {}, {}
+        for i, (n, ln) in enumerate(zip(names, lens)):
+            a = rng.standard_normal((ln, 6)).astype(np.float32)
+            b = rng.standard_normal((1, ln, 4) if i == 2 else (ln, 4)).astype(np.float32)   # doc02: stray leading unit dim
+            np.save(os.path.join(da, n), a), np.save(os.path.join(db, n), b)
+            lab = (rng.random(ln) < 0.35).astype(int).tolist()
+            if i == 4:
+                lab = []                      # "has no data": skipped
+            if i == 5:
+                lab = [0] * ln                # no positive boundary: kept with a warning
+            lab = list(lab)
+            if i == 6 and ln:
+                lab[-1] = 1                   # last label is forced to 0 by the loader
+            labs[n[:-4]] = lab
+            times[n[:-4]] = rng.random((ln, 2)).astype(np.float32).tolist()
+            out[f'in.text.{n}'], out[f'in.audio.{n}'] = a, b
+            out[f'in.labs.{n}'] = np.array(lab, dtype=np.int64)
+            out[f'in.times.{n}'] = np.array(times[n[:-4]], dtype=np.float32)
+        lab_file, time_file, split_file = os.path.join(tmp, 'labs_dict.pkl'), os.path.join(tmp, 'times.pkl'), os.path.join(tmp, 'split.json')
+        with open(lab_file, 'wb') as f:
+            pickle.dump(labs, f)
+        with open(time_file, 'wb') as f:
+            pickle.dump(times, f)
+        split = {'train': names[:6], 'test': names[6:9], 'validation': names[9:]}
+        with open(split_file, 'w') as f:
+            json.dump(split, f)
+        out['split.train'], out['split.test'], out['split.validation'] = (np.array(split[k]) for k in ('train', 'test', 'validation'))
+
+        def pack(prefix, items):
+            out[prefix + '.names'] = np.array([it[2] for it in items])
+            for j, it in enumerate(items):
+                out[f'{prefix}.{j}.embs'] = it[0].numpy()
+                out[f'{prefix}.{j}.labs'] = np.array(it[1], dtype=np.int64)
+
+        for tag, kw in (('split', {}), ('split_times', {'timing_info': time_file})):
+            with open(lab_file, 'wb') as f:       # the loader mutates the label lists it unpickles: start from a fresh pickle
+                pickle.dump(labs, f)
+            res = load_dataset_from_precomputed(da + '+' + db, lab_file, split=split_file, **kw)
+            assert len(res) == 1 and len(res[0]) == 3
+            for part, items in zip(('train', 'test', 'validation'), res[0]):
+                pack(f'out.{tag}.{part}', items)
+        folds = load_dataset_from_precomputed(da + '+' + db, lab_file, k_folds=5)
+        out['out.folds.n'] = np.array(len(folds))
+        for i, (tr, te) in enumerate(folds):
+            out[f'out.folds.{i}.train'] = np.array(sorted(it[2] for it in tr))
+            out[f'out.folds.{i}.test_size'] = np.array(len(te))
+        data, files = load_dataset_for_inference(da)
+        out['out.inference.files'] = np.array(sorted(files))
+        out['out.inference.shapes'] = np.array([list(data[files.index(f)].shape) for f in sorted(files)])
+    save('g12_loader', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g7', 'g3a', 'g3b', 'g3c', 'g2', 'g4', 'g5', 'g6', 'g8', 'g9', 'g10', 'g11']
+    which = sys.argv[1:] or ['g1', 'g7', 'g3a', 'g3b', 'g3c', 'g2', 'g4', 'g5', 'g6', 'g8', 'g9', 'g10', 'g11', 'g12']
     for w in which:
         if w == 'g1':
             g1_bilstm()
@@ -418,6 +485,8 @@ if __name__ == '__main__':
             g8_collater()
         elif w == 'g9':
             g9_init()
+        elif w == 'g12':
+            g12_loader()
         elif w == 'g10':
             g10_legacy()
         elif w == 'g11':
