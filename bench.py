@@ -96,11 +96,19 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)')
+    # MTS_BENCH_REHEARSAL=1: every rank on cuda:0 over gloo -- exercises the N>1 code path (sharding, gradient-ready hooks,
+    # async exchange, max-over-ranks timing) on a one-GPU box; the numbers it prints mean nothing
+    rehearsal = os.environ.get('MTS_BENCH_REHEARSAL') == '1'
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=device)          # backend "nccl" is RCCL on ROCm
+        if rehearsal:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=device)      # backend "nccl" is RCCL on ROCm
 
     from multimodaltopicsegmentation_amd import ops
     from multimodaltopicsegmentation_amd.rnn_taggers import BiLSTM, BiLSTMLateFusion, BiRnnCrf
