@@ -340,3 +340,69 @@ def test_transformer_padded_to_3600_sentences(dtype):
             for i in range(n):
                 if abs(float(prob[b, i]) - 0.5) > 1e-4:
                     assert tags[b][i] == ref_tags[b][i], (b, i)
+
+
+# ------------------------------------------------------------------------------------------------ recurrent taggers at production widths, bf16
+def test_bilstm_1792_bf16_matrix_core_recurrence():
+    """g2 fixture (D=1792, H=256, 2 layers) in bf16: the CU-pair MFMA recurrence kernels + MFMA input projections.
+    Stated bf16 bars: logits 8e-2 abs, loss 2e-2 rel, boundaries equal where the reference probability is >= 0.03 from 0.5."""
+    from multimodaltopicsegmentation_amd import BiLSTM
+    g = H.load('g2_bilstm_1792')
+    D, Hd, NL = [int(v) for v in g['cfg']]
+    shapes = H.bilstm_param_shapes(D, Hd, NL, 1)
+    shapes['classification.weight'] = (1, 2 * Hd)
+    shapes['classification.bias'] = (1,)
+    m = _load_into(BiLSTM(2, D, Hd, num_layers=NL, loss_fn='FocalLoss', compute_dtype='bf16'),
+                   {k: H.seeded_param(k, s, int(g['seed'])) for k, s in shapes.items()})
+    x = torch.from_numpy(g['x'].astype(np.float32)).to(DEV)
+    lengths, tags = torch.from_numpy(g['lengths']), torch.from_numpy(g['tags']).to(DEV)
+    loss = m.loss(x, lengths, tags)
+    loss.backward()
+    assert abs(loss.item() - float(g['loss'])) < 2e-2 * max(1.0, abs(float(g['loss'])))
+    m.th = 0.5
+    scores, got = m(x, lengths)
+    np.testing.assert_allclose(scores.cpu().numpy(), g['scores'], atol=8e-2, rtol=0)
+    _margin_equal(got, H.split_tags(g['tags0.5'], g['lengths'].tolist()), g['scores'], g['lengths'].tolist(), 0.5, 0.03)
+    for n, p in m.named_parameters():
+        got_g = p.grad.detach().float().cpu().numpy()
+        ref = g['gsum.' + n]
+        # checksum = (sum, sum |.|, sum of squares)-style aggregates: bf16 keeps the magnitudes to a few percent
+        np.testing.assert_allclose(H.checksum(got_g)[1:], ref[1:], rtol=8e-2, atol=1e-6, err_msg=n)
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_late_fusion_1024_768_against_oracle(dtype):
+    """C5 widths (OpenL3 mean+std 1024-d audio, RoBERTa 768-d text; H=256, 2 layers), ragged batch incl. a length-1 document."""
+    from oracle import restatement as R
+    from multimodaltopicsegmentation_amd import BiLSTMLateFusion
+    B, L, D1, D2, Hd, NL = 5, 40, 1024, 768, 256, 2
+    m = BiLSTMLateFusion(2, [D1, D2], Hd, num_layers=NL, loss_fn='FocalLoss', compute_dtype=dtype, seed=5).to(DEV)
+    g = torch.Generator().manual_seed(77)
+    lengths = torch.tensor([40, 31, 1, 17, 40])
+    x1, x2 = torch.randn(B, L, D1, generator=g), torch.randn(B, L, D2, generator=g)
+    y = torch.full((B, L), -1.0)
+    for b, n in enumerate(lengths.tolist()):
+        x1[b, n:] = 0.0
+        x2[b, n:] = 0.0
+        y[b, :n] = (torch.rand(n, generator=g) < 0.2).float()
+    p = {k: v.detach().cpu().double().requires_grad_(True) for k, v in m.state_dict().items()}
+    ref = R.late_fusion_scores(x1.double(), x2.double(), lengths, p, NL)
+    ref_loss = R.tagger_loss(ref, lengths, y.double(), 'FocalLoss')
+    ref_loss.backward()
+    f32 = dtype == 'fp32'
+    loss = m.loss(x1.to(DEV), x2.to(DEV), lengths, y.to(DEV))
+    loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < (3e-6 if f32 else 2e-2) * max(1.0, abs(ref_loss.item()))
+    m.th = 0.5
+    scores, tags = m(x1.to(DEV), x2.to(DEV), lengths)
+    got = scores.cpu().double()
+    for b, n in enumerate(lengths.tolist()):
+        assert (got[b, :n] - ref[b, :n].detach()).abs().max().item() < (5e-5 if f32 else 8e-2)
+    assert [len(t) for t in tags] == lengths.tolist()
+    ref_g = {k: v.grad for k, v in p.items() if v.grad is not None}
+    for n, prm in m.named_parameters():
+        if n not in ref_g:
+            continue
+        a, r = prm.grad.detach().cpu().double(), ref_g[n]
+        scale = max(float(r.abs().max()), 1e-9)
+        assert float((a - r).abs().max()) < (2e-3 if f32 else 0.12) * scale + (1e-7 if f32 else 2e-4), n
