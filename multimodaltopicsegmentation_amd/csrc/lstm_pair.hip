@@ -8,8 +8,9 @@
 // sequence and there is NO weight traffic in the time loop.  What the pair exchanges per step is the new h of its
 // half (16 docs x 128 units bf16 = 4 KiB) as 8-byte {tag = step+1, 2 x bf16} granules written with agent-scope
 // atomic stores and polled with agent-scope atomic loads (the data is its own flag: no fence, no separate flag
-// word; cdna guide G16/R2).  Each pair serves TWO groups of 16 documents alternately, so a group's exchange latency
-// is covered by the other group's compute.
+// word; cdna guide G16/R2).  A pair can serve LP_GROUPS groups of 16 documents alternately so that one group's exchange
+// latency is covered by the other's compute; at B = 64 that measured SLOWER (9.0 us per step for two groups vs 4.9 us for
+// one: it halves the number of pairs while 97 % of the CUs idle), hence LP_GROUPS = 1.
 //
 // Safety: both workgroups of a pair are co-resident by construction (the grid is a few dozen workgroups at most);
 // every spin is bounded and a timeout sets a status word instead of hanging; the exchange buffer is zeroed by a
@@ -20,7 +21,7 @@
 #include "common.h"
 
 #define LP_DOCS 16
-#define LP_GROUPS 2
+#define LP_GROUPS 1
 #define LP_SPIN_LIMIT (1u << 22)
 
 typedef unsigned long long u64;
