@@ -34,12 +34,19 @@ def fwd_bwd_mflop_per_sentence(D, ff, radius, n_layers, n_out=1):
     return macs * 2 * 3 / 1e6
 
 
-def synthetic_batch(B, L, D, rank, device, D2=None):
+def synthetic_batch(B, L, D, rank, device, D2=None, ragged=False):
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.randn(B, L, D, generator=g)
     y = (torch.rand(B, L, generator=g) < 0.05).float()
     y[:, -1] = 0.0                                             # utils/load_datasets_precomputed.py:172
-    batch = {'src_tokens': x.to(device), 'src_lengths': torch.full((B,), L, dtype=torch.int64), 'tgt_tokens': y.to(device),
+    lengths = torch.full((B,), L, dtype=torch.int64)
+    if ragged:                                                 # len ~ U{L/4 .. L}, zero-padded, targets padded with -1
+        lengths = torch.randint(L // 4, L + 1, (B,), generator=g)
+        for b, n in enumerate(lengths.tolist()):
+            x[b, n:] = 0.0
+            y[b, n:] = -1.0
+            y[b, n - 1] = 0.0
+    batch = {'src_tokens': x.to(device), 'src_lengths': lengths, 'tgt_tokens': y.to(device),
              'src_tokens2': None, 'id': torch.arange(B), 'domain': None}
     if D2:
         batch['src_tokens2'] = torch.randn(B, L, D2, generator=g).to(device)
@@ -88,6 +95,8 @@ def main():
     ap.add_argument('--cpu-docs', type=int, default=8)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true')
+    ap.add_argument('--ragged', action='store_true', help='ragged lengths U{L/4..L} (value counts valid sentences only)')
+    ap.add_argument('--no-pack', action='store_true', help='with --ragged: keep the padded rows in the encoder (A/B of the packed training path)')
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -142,7 +151,9 @@ def main():
         wl = f'late fusion (concat) two BiLSTMs {D}+{D2} H=256 layers={n_layers} focal loss'
     model = model.to(device)
     trainer = NativeTrainer(model, lr=1e-3, optimizer='Adam')
-    batch = synthetic_batch(args.docs, args.seq, D, rank, device, D2)
+    batch = synthetic_batch(args.docs, args.seq, D, rank, device, D2, ragged=args.ragged)
+    if args.no_pack and hasattr(model, 'pack_rows'):
+        model.pack_rows = False
 
     def sync():
         torch.cuda.synchronize()
@@ -177,14 +188,14 @@ def main():
         elapsed = float(t)
 
     if rank == 0:
-        sentences = world * args.docs * args.seq * args.steps
+        sentences = world * int(batch['src_lengths'].sum()) * args.steps      # valid sentences (= docs x seq unless --ragged)
         value = sentences / elapsed
         out = {
             'metric': 'sentences/sec (fwd+bwd)', 'value': value, 'unit': 'sentences/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'BASELINE configs[1]: {wl}, {args.docs} docs x {args.seq} sentences per GPU, '
-                                   f'fwd+bwd+Adam(eps 1e-7), inputs resident in HBM',
+                                   f'fwd+bwd+Adam(eps 1e-7), inputs resident in HBM' + (', ragged lengths U{L/4..L}' + (' (padded rows kept)' if args.no_pack else ' (packed)') if args.ragged else ''),
                        'global_batch_docs': world * args.docs, 'sentences_per_doc': args.seq, 'parallelism': f'dp{world} (document-sharded, RCCL all-reduce)'},
             'final_loss': loss_val,
         }

@@ -98,7 +98,7 @@ int mts_cast(void* stream, int dst_dtype, const float* src, void* dst, size_t n)
  * pre (act dtype, optional) receives the pre-LN sum for the backward; mean/rstd fp32 [B*L]. */
 int mts_embed_layernorm_fwd(void* stream, int dtype, int B, int L, int D, const float* x, const float* pos,
                             int pos_offset, const float* type0, const float* gamma, const float* beta, float eps,
-                            void* y, void* pre, float* mean, float* rstd);
+                            void* y, void* pre, float* mean, float* rstd, const int32_t* row_src, int n_rows);
 /* If head_w != NULL the tagger head is fused in: scores[r,c] = y[r,:].head_w[c,:] + head_b[c] (fp32 [rows,n_out],
  * n_out <= 4), computed on the stored (act dtype) y.  models/CRF.py:579 on top of modeling_longformer.py:1127-1131. */
 int mts_layernorm_fwd(void* stream, int dtype, int rows, int D, const void* x, const float* gamma,
@@ -116,10 +116,20 @@ int mts_layernorm_bwd(void* stream, int dtype, int rows, int D, const void* x, c
                       void* dx, float* dgamma, float* dbeta, float* dxsum, void* partial);
 /* gradient of the position table: dpos[pos_offset+i,:] += sum_b dpre[b,i,:].  (The token-type row's gradient is
  * sum_{b,i} dpre = the `dxsum` output of the embedding LayerNorm's mts_layernorm_bwd.) */
-int mts_embed_bwd(void* stream, int dtype, int B, int L, int D, const void* dpre, float* dpos, int pos_offset);
+int mts_embed_bwd(void* stream, int dtype, int B, int L, int D, const void* dpre, float* dpos, int pos_offset,
+                  const int32_t* row0, const int32_t* lengths);
 
 /* dy *= gelu_erf'(u) in place (FFN backward; modeling_longformer.py:1113-1116); n elements, n % 4 == 0 */
 int mts_gelu_bwd(void* stream, int dtype, size_t n, const void* u, void* dy);
+
+/* ---------------------------------------------------------------------------------------------
+ * PACKED BATCHES (training path; the reference pads every Transformer batch to 3600 sentences, train_fit.py:104-106,
+ * and runs all of them through the encoder).  Activations may hold only the valid sentences, document after document:
+ * n_rows = sum of lengths; `row_src[r]` = b*L + i names the sentence of the padded batch that packed row r holds
+ * (mts_embed_layernorm_fwd gathers x and the position, mts_tagger_loss finds the target); `row0[b]` = first packed row of
+ * document b (band attention, mts_embed_bwd).  All four are NULL for the padded [B, L] layout.  Padded rows never
+ * influence valid rows or any gradient (masked as keys, excluded from the loss), so results on valid rows are the same.
+ * ------------------------------------------------------------------------------------------- */
 
 /* ---------------------------------------------------------------------------------------------
  * Restricted-window (band) self-attention.
@@ -133,7 +143,7 @@ int mts_gelu_bwd(void* stream, int dtype, size_t n, const void* u, void* dy);
  * ------------------------------------------------------------------------------------------- */
 int mts_band_slots(int radius);
 int mts_band_attn_fwd(void* stream, int dtype, int B, int L, int D, int heads, int radius,
-                      const void* qkv, const int32_t* lengths, void* ctx, float* probs);
+                      const void* qkv, const int32_t* lengths, void* ctx, float* probs, const int32_t* row0);
 /* dqkv [B*L, 3D] (dq already multiplied by q_scale so it is the gradient wrt the unscaled projection);
  * dscores: fp32 scratch of the same size as probs.  dbias (optional): fp32 [3D] column sums of dqkv as stored =
  * the gradient of the q/k/v biases (modeling_longformer.py:504-506), produced from the kernels' output tiles instead of
@@ -141,7 +151,7 @@ int mts_band_attn_fwd(void* stream, int dtype, int B, int L, int D, int heads, i
 size_t mts_band_attn_bwd_workspace(int B, int L, int D);
 int mts_band_attn_bwd(void* stream, int dtype, int B, int L, int D, int heads, int radius, float q_scale,
                       const void* qkv, const int32_t* lengths, const float* probs, const void* dctx,
-                      void* dqkv, float* dscores, float* dbias, void* workspace);
+                      void* dqkv, float* dscores, float* dbias, void* workspace, const int32_t* row0, int n_rows);
 
 /* ---------------------------------------------------------------------------------------------
  * Tagger head tail: loss + its gradient, and greedy decode.
@@ -155,7 +165,8 @@ int mts_band_attn_bwd(void* stream, int dtype, int B, int L, int D, int heads, i
 size_t mts_tagger_loss_workspace(int B, int L);
 int mts_tagger_loss(void* stream, int loss_kind, int B, int L, int Lt, int n_out, const float* scores,
                     const float* targets, const int32_t* lengths, float alpha, float gamma,
-                    float* loss_out, float* dscores, void* workspace, size_t workspace_bytes);
+                    float* loss_out, float* dscores, void* workspace, size_t workspace_bytes,
+                    const int32_t* row_src, int n_rows);
 /* tags_out: uint8 [B, L]; positions >= length are 0.  prob > threshold, strict. */
 int mts_greedy_decode(void* stream, int B, int L, int n_out, const float* scores, const int32_t* lengths,
                       float threshold, uint8_t* tags_out);

@@ -36,18 +36,18 @@ SIGNATURES = {
     'mts_colsum_workspace': (_sz, [_i]),
     'mts_colsum': (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     'mts_cast': (_i, [_vp, _i, _vp, _vp, _sz]),
-    'mts_embed_layernorm_fwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
+    'mts_embed_layernorm_fwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i]),
     'mts_layernorm_fwd': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'mts_layernorm_bwd_workspace': (_sz, [_i]),
     'mts_layernorm_bwd': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    'mts_embed_bwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i]),
+    'mts_embed_bwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     'mts_gelu_bwd': (_i, [_vp, _i, _sz, _vp, _vp]),
     'mts_band_slots': (_i, [_i]),
-    'mts_band_attn_fwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'mts_band_attn_fwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'mts_band_attn_bwd_workspace': (_sz, [_i, _i, _i]),
-    'mts_band_attn_bwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'mts_band_attn_bwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
     'mts_tagger_loss_workspace': (_sz, [_i, _i]),
-    'mts_tagger_loss': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _sz]),
+    'mts_tagger_loss': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _sz, _vp, _i]),
     'mts_greedy_decode': (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp]),
     'mts_head_fwd': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     'mts_head_bwd_params': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),

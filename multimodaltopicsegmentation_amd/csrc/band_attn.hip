@@ -113,18 +113,19 @@ __global__ __launch_bounds__(256) void band_fwd_kernel(const BandArgs a) {
   const int ntiles = (a.L + TQ - 1) / TQ;
   int tile, h, b;
   decode_block(ntiles, a.heads, ntiles * a.heads * a.B, tile, h, b);
+  const DocView doc = doc_view(a, b);
   const int i0 = tile * TQ;
   const int len = a.lengths ? min(a.lengths[b], a.L) : a.L;
   const int tq = threadIdx.x >> 3, g = threadIdx.x & 7;
   const int i = i0 + tq;
   const int w = a.radius, W = 2 * w + 1, hd = a.hd, ld = 3 * a.D;
-  const T* qbase = reinterpret_cast<const T*>(a.qkv) + (size_t)b * a.L * ld + h * hd;
+  const T* qbase = reinterpret_cast<const T*>(a.qkv) + (size_t)doc.base * ld + h * hd;
   const int nsb = a.slots / 32;
 
-  stage_rows<T>(Qs, a.rs, qbase, ld, i0, TQ, a.L, hd);
+  stage_rows<T>(Qs, a.rs, qbase, ld, i0, TQ, doc.Lb, hd);
   for (int sb = 0; sb < nsb; ++sb) {
     __syncthreads();   // previous block's readers are done with KVs (and Qs is complete after the first pass)
-    stage_rows<T>(KVs, a.rs, qbase + a.D, ld, i0 - w + 32 * sb, KV_ROWS, a.L, hd);
+    stage_rows<T>(KVs, a.rs, qbase + a.D, ld, i0 - w + 32 * sb, KV_ROWS, doc.Lb, hd);
     __syncthreads();
     float s[4];
     score_phase<T>(Qs, KVs, a.rs, hd, tq, g, s);
@@ -151,11 +152,11 @@ __global__ __launch_bounds__(256) void band_fwd_kernel(const BandArgs a) {
     }
     sum = oct_sum(sum);
     const float inv = qok ? 1.0f / sum : 0.f;
-    float* prow = a.probs + ((size_t)(b * a.L + i) * a.heads + h) * a.slots;
+    float* prow = a.probs + ((size_t)(doc.base + i) * a.heads + h) * a.slots;
     for (int c = g; c < a.slots; c += 8) {
       const float p = Ps[tq * a.ps + c] * inv;
       Ps[tq * a.ps + c] = p;
-      if (i < a.L) prow[c] = p;
+      if (i < doc.Lb) prow[c] = p;
     }
   }
   float acc[MAXU][4];
@@ -163,13 +164,13 @@ __global__ __launch_bounds__(256) void band_fwd_kernel(const BandArgs a) {
   for (int uu = 0; uu < MAXU; ++uu) acc[uu][0] = acc[uu][1] = acc[uu][2] = acc[uu][3] = 0.f;
   for (int sb = 0; sb < nsb; ++sb) {
     __syncthreads();
-    stage_rows<T>(KVs, a.rs, qbase + 2 * a.D, ld, i0 - w + 32 * sb, KV_ROWS, a.L, hd);
+    stage_rows<T>(KVs, a.rs, qbase + 2 * a.D, ld, i0 - w + 32 * sb, KV_ROWS, doc.Lb, hd);
     __syncthreads();
     const int ncc = min(32, W - 32 * sb);
     accum_phase<T, MAXU>(Ps + tq * a.ps + 32 * sb, 1, KVs, a.rs, hd, tq, g, ncc, acc);
   }
-  if (i < a.L) {
-    T* o = reinterpret_cast<T*>(a.ctx) + (size_t)(b * a.L + i) * a.D + h * hd;
+  if (i < doc.Lb) {
+    T* o = reinterpret_cast<T*>(a.ctx) + (size_t)(doc.base + i) * a.D + h * hd;
     const int nch = hd / 4;
 #pragma unroll
     for (int uu = 0; uu < MAXU; ++uu) {
@@ -192,28 +193,29 @@ __global__ __launch_bounds__(256) void band_bwd_q_kernel(const BandArgs a) {
   const int ntiles = (a.L + TQ - 1) / TQ;
   int tile, h, b;
   decode_block(ntiles, a.heads, ntiles * a.heads * a.B, tile, h, b);
+  const DocView doc = doc_view(a, b);
   const int i0 = tile * TQ;
   const int tq = threadIdx.x >> 3, g = threadIdx.x & 7;
   const int i = i0 + tq;
   const int w = a.radius, W = 2 * w + 1, hd = a.hd, ld = 3 * a.D;
-  const T* qbase = reinterpret_cast<const T*>(a.qkv) + (size_t)b * a.L * ld + h * hd;
-  const T* dcbase = reinterpret_cast<const T*>(a.dctx) + (size_t)b * a.L * a.D + h * hd;
+  const T* qbase = reinterpret_cast<const T*>(a.qkv) + (size_t)doc.base * ld + h * hd;
+  const T* dcbase = reinterpret_cast<const T*>(a.dctx) + (size_t)doc.base * a.D + h * hd;
   const int nsb = a.slots / 32;
-  const size_t prow_off = ((size_t)(b * a.L + min(i, a.L - 1)) * a.heads + h) * a.slots;
+  const size_t prow_off = ((size_t)(doc.base + min(i, doc.Lb - 1)) * a.heads + h) * a.slots;
   const float* prow = a.probs + prow_off;
 
-  stage_rows<T>(Qs, a.rs, dcbase, a.D, i0, TQ, a.L, hd);
+  stage_rows<T>(Qs, a.rs, dcbase, a.D, i0, TQ, doc.Lb, hd);
   float delta = 0.f;
   for (int sb = 0; sb < nsb; ++sb) {
     __syncthreads();
-    stage_rows<T>(KVs, a.rs, qbase + 2 * a.D, ld, i0 - w + 32 * sb, KV_ROWS, a.L, hd);   // V rows
+    stage_rows<T>(KVs, a.rs, qbase + 2 * a.D, ld, i0 - w + 32 * sb, KV_ROWS, doc.Lb, hd);   // V rows
     __syncthreads();
     float s[4];
     score_phase<T>(Qs, KVs, a.rs, hd, tq, g, s);     // dP
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int c = 32 * sb + g + 8 * t;
-      const float p = (i < a.L) ? prow[c] : 0.f;      // zero for masked keys / queries and for c >= W
+      const float p = (i < doc.Lb) ? prow[c] : 0.f;      // zero for masked keys / queries and for c >= W
       Ps[tq * a.ps + c] = s[t];
       delta += p * s[t];
     }
@@ -223,10 +225,10 @@ __global__ __launch_bounds__(256) void band_bwd_q_kernel(const BandArgs a) {
   {
     float* dsrow = a.dscores + prow_off;
     for (int c = g; c < a.slots; c += 8) {
-      const float p = (i < a.L) ? prow[c] : 0.f;
+      const float p = (i < doc.Lb) ? prow[c] : 0.f;
       const float ds = p * (Ps[tq * a.ps + c] - delta);
       Ps[tq * a.ps + c] = ds;
-      if (i < a.L) dsrow[c] = ds;
+      if (i < doc.Lb) dsrow[c] = ds;
     }
   }
   float acc[MAXU][4];
@@ -234,13 +236,13 @@ __global__ __launch_bounds__(256) void band_bwd_q_kernel(const BandArgs a) {
   for (int uu = 0; uu < MAXU; ++uu) acc[uu][0] = acc[uu][1] = acc[uu][2] = acc[uu][3] = 0.f;
   for (int sb = 0; sb < nsb; ++sb) {
     __syncthreads();
-    stage_rows<T>(KVs, a.rs, qbase + a.D, ld, i0 - w + 32 * sb, KV_ROWS, a.L, hd);       // K rows
+    stage_rows<T>(KVs, a.rs, qbase + a.D, ld, i0 - w + 32 * sb, KV_ROWS, doc.Lb, hd);       // K rows
     __syncthreads();
     const int ncc = min(32, W - 32 * sb);
     accum_phase<T, MAXU>(Ps + tq * a.ps + 32 * sb, 1, KVs, a.rs, hd, tq, g, ncc, acc);
   }
-  if (i < a.L) {
-    T* o = reinterpret_cast<T*>(a.dqkv) + (size_t)(b * a.L + i) * ld + h * hd;
+  if (i < doc.Lb) {
+    T* o = reinterpret_cast<T*>(a.dqkv) + (size_t)(doc.base + i) * ld + h * hd;
     const int nch = hd / 4;
 #pragma unroll
     for (int uu = 0; uu < MAXU; ++uu) {
@@ -276,15 +278,16 @@ __global__ __launch_bounds__(256) void band_bwd_kv_kernel(const BandArgs a) {
   const int ntiles = (a.L + TQ - 1) / TQ;
   int tile, h, b;
   decode_block(ntiles, a.heads, ntiles * a.heads * a.B, tile, h, b);
+  const DocView doc = doc_view(a, b);
   const int j0 = tile * TQ;
   const int tk = threadIdx.x >> 3, g = threadIdx.x & 7;
   const int j = j0 + tk;
   const int w = a.radius, W = 2 * w + 1, hd = a.hd, ld = 3 * a.D;
-  const T* qbase = reinterpret_cast<const T*>(a.qkv) + (size_t)b * a.L * ld + h * hd;
-  const T* dcbase = reinterpret_cast<const T*>(a.dctx) + (size_t)b * a.L * a.D + h * hd;
+  const T* qbase = reinterpret_cast<const T*>(a.qkv) + (size_t)doc.base * ld + h * hd;
+  const T* dcbase = reinterpret_cast<const T*>(a.dctx) + (size_t)doc.base * a.D + h * hd;
   const size_t xrow = (size_t)a.heads * a.slots;
-  const float* dsb = a.dscores + ((size_t)b * a.L * a.heads + h) * a.slots;
-  const float* pb = a.probs + ((size_t)b * a.L * a.heads + h) * a.slots;
+  const float* dsb = a.dscores + ((size_t)doc.base * a.heads + h) * a.slots;
+  const float* pb = a.probs + ((size_t)doc.base * a.heads + h) * a.slots;
   const int nsb = a.slots / 32;
 
   float dk[MAXU][4], dv[MAXU][4];
@@ -299,9 +302,9 @@ __global__ __launch_bounds__(256) void band_bwd_kv_kernel(const BandArgs a) {
     const int ncc = min(32, W - 32 * sb);
     for (int pass = 0; pass < 2; ++pass) {
       __syncthreads();
-      stage_coef(raw, pass == 0 ? dsb : pb, xrow, first_i, a.L, cbase, W);
-      if (pass == 0) stage_rows<T>(Rs, a.rs, qbase, ld, first_i, KV_ROWS, a.L, hd);          // scaled q rows
-      else stage_rows<T>(Rs, a.rs, dcbase, a.D, first_i, KV_ROWS, a.L, hd);                  // dCtx rows
+      stage_coef(raw, pass == 0 ? dsb : pb, xrow, first_i, doc.Lb, cbase, W);
+      if (pass == 0) stage_rows<T>(Rs, a.rs, qbase, ld, first_i, KV_ROWS, doc.Lb, hd);          // scaled q rows
+      else stage_rows<T>(Rs, a.rs, dcbase, a.D, first_i, KV_ROWS, doc.Lb, hd);                  // dCtx rows
       __syncthreads();
       for (int cc = g; cc < 32; cc += 8) PT[tk * 33 + cc] = raw[(tk + cc) * 32 + (31 - cc)];
       __syncthreads();
@@ -309,8 +312,8 @@ __global__ __launch_bounds__(256) void band_bwd_kv_kernel(const BandArgs a) {
       else accum_phase<T, MAXU>(PT + tk * 33, 1, Rs, a.rs, hd, tk, g, ncc, dv);
     }
   }
-  if (j < a.L) {
-    T* o = reinterpret_cast<T*>(a.dqkv) + (size_t)(b * a.L + j) * ld + h * hd;
+  if (j < doc.Lb) {
+    T* o = reinterpret_cast<T*>(a.dqkv) + (size_t)(doc.base + j) * ld + h * hd;
     const int nch = hd / 4;
 #pragma unroll
     for (int uu = 0; uu < MAXU; ++uu) {
@@ -346,7 +349,7 @@ static int band_fill(BandArgs& a, int dtype, int B, int L, int D, int heads, int
   a.rs = band_row_stride(hd, dtype == MTS_F32 ? 4 : 2);
   a.ps = a.slots + 1;
   a.q_scale = 1.f;
-  a.bias_slab = nullptr; a.img_bytes = 0;
+  a.bias_slab = nullptr; a.img_bytes = 0; a.row0 = nullptr;
   a.lengths = nullptr; a.qkv = nullptr; a.ctx = nullptr; a.probs = nullptr; a.dctx = nullptr; a.dqkv = nullptr; a.dscores = nullptr;
   return MTS_OK;
 }
@@ -373,11 +376,13 @@ static int band_fwd_launch(const BandArgs& a, hipStream_t st) {
 }
 
 extern "C" int mts_band_attn_fwd(void* stream, int dtype, int B, int L, int D, int heads, int radius, const void* qkv, const int32_t* lengths,
-                                 void* ctx, float* probs) {
+                                 void* ctx, float* probs, const int32_t* row0) {
   BandArgs a;
   int rc = band_fill(a, dtype, B, L, D, heads, radius, "mts_band_attn_fwd");
   if (rc) return rc;
   MTS_CHECK_ARG(qkv && ctx && probs, "mts_band_attn_fwd: null pointer");
+  MTS_CHECK_ARG(!row0 || lengths, "mts_band_attn_fwd: packed rows (row0) need lengths");
+  a.row0 = row0;
   a.qkv = qkv; a.lengths = lengths; a.ctx = ctx; a.probs = probs;
   if (dtype == MTS_BF16 && g_band_mfma) {
     rc = mts_band_mfma_fwd(a, (hipStream_t)stream);
@@ -417,12 +422,14 @@ extern "C" size_t mts_band_attn_bwd_workspace(int B, int L, int D) {
 
 extern "C" int mts_band_attn_bwd(void* stream, int dtype, int B, int L, int D, int heads, int radius, float q_scale, const void* qkv,
                                  const int32_t* lengths, const float* probs, const void* dctx, void* dqkv, float* dscores, float* dbias,
-                                 void* workspace) {
+                                 void* workspace, const int32_t* row0, int n_rows) {
   BandArgs a;
   int rc = band_fill(a, dtype, B, L, D, heads, radius, "mts_band_attn_bwd");
   if (rc) return rc;
   MTS_CHECK_ARG(qkv && probs && dctx && dqkv && dscores, "mts_band_attn_bwd: null pointer");
   MTS_CHECK_ARG(!dbias || workspace, "mts_band_attn_bwd: dbias needs mts_band_attn_bwd_workspace() bytes of workspace");
+  MTS_CHECK_ARG(!row0 || (lengths && n_rows > 0 && n_rows <= B * L), "mts_band_attn_bwd: packed rows (row0) need lengths and 0 < n_rows <= B*L");
+  a.row0 = row0;
   a.qkv = qkv; a.lengths = lengths; a.probs = const_cast<float*>(probs); a.dctx = dctx; a.dqkv = dqkv; a.dscores = dscores;
   a.q_scale = q_scale;
   if (dtype == MTS_BF16 && g_band_mfma) {
@@ -433,6 +440,6 @@ extern "C" int mts_band_attn_bwd(void* stream, int dtype, int B, int L, int D, i
     a.bias_slab = nullptr;
   }
   rc = dtype == MTS_F32 ? band_bwd_launch<float>(a, (hipStream_t)stream) : band_bwd_launch<bf16_t>(a, (hipStream_t)stream);
-  if (rc == MTS_OK && dbias) rc = mts_colsum(stream, dtype, B * L, 3 * D, dqkv, 3 * D, dbias, 0, workspace);
+  if (rc == MTS_OK && dbias) rc = mts_colsum(stream, dtype, row0 ? n_rows : B * L, 3 * D, dqkv, 3 * D, dbias, 0, workspace);
   return rc;
 }

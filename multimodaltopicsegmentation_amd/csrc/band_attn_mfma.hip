@@ -167,9 +167,12 @@ __global__ __launch_bounds__(256, OCC) void band_mfma_fwd_kernel(const BandArgs 
   decode_block(ntiles, a.heads, ntiles * a.heads * a.B, tile, h, b);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
   const int t0 = tile * TROWS, q0 = t0 + WROWS * wave;
-  const int w = a.radius, W = 2 * w + 1, hd = a.hd, ld = 3 * a.D, L = a.L;
+  const int w = a.radius, W = 2 * w + 1, hd = a.hd, ld = 3 * a.D;
+  const DocView doc = doc_view(a, b);
+  const int L = doc.Lb;                     // rows of this document (packed batches: its length)
+  if (t0 >= L) return;                     // packed batches: this document has no rows in the tile (uniform: before any barrier)
   const int len = a.lengths ? min(a.lengths[b], L) : L;
-  const bf16_t* qbase = reinterpret_cast<const bf16_t*>(a.qkv) + (size_t)b * L * ld + h * hd;
+  const bf16_t* qbase = reinterpret_cast<const bf16_t*>(a.qkv) + (size_t)doc.base * ld + h * hd;
 
   stage_dma<KK>(img, qbase + 2 * a.D, ld, t0 - w, TROWS - WROWS + 16 * NKB, L);      // V rows
 
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(256, OCC) void band_mfma_fwd_kernel(const BandArgs 
   for (int qb = 0; qb < 2; ++qb) {
     const int i = q0 + 16 * qb + l15;
     if (i < L) {
-      float* prow = a.probs + ((size_t)(b * L + i) * a.heads + h) * a.slots;
+      float* prow = a.probs + ((size_t)(doc.base + i) * a.heads + h) * a.slots;
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256, OCC) void band_mfma_fwd_kernel(const BandArgs 
 #pragma unroll
   for (int s = 0; s < NKB / 2; ++s) { lo[s] = WROWS * wave + 32 * s + 4 * g; hi[s] = lo[s] + 16; }
   cv_phase<KK, NKB / 2>(img, lo, hi, coef, lane, o);
-  emit_rows<KK>(img, nullptr, reinterpret_cast<bf16_t*>(a.ctx) + (size_t)b * L * a.D + h * hd, a.D, q0, L, 1.f, o, nullptr);
+  emit_rows<KK>(img, nullptr, reinterpret_cast<bf16_t*>(a.ctx) + (size_t)doc.base * a.D + h * hd, a.D, q0, L, 1.f, o, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -256,9 +259,15 @@ __global__ __launch_bounds__(256, OCC) void band_mfma_bwd_q_kernel(const BandArg
   decode_block(ntiles, a.heads, ntiles * a.heads * a.B, tile, h, b);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
   const int t0 = tile * TROWS, q0 = t0 + WROWS * wave;
-  const int w = a.radius, W = 2 * w + 1, hd = a.hd, ld = 3 * a.D, L = a.L;
-  const bf16_t* qbase = reinterpret_cast<const bf16_t*>(a.qkv) + (size_t)b * L * ld + h * hd;
-  const bf16_t* dcbase = reinterpret_cast<const bf16_t*>(a.dctx) + (size_t)b * L * a.D + h * hd;
+  const int w = a.radius, W = 2 * w + 1, hd = a.hd, ld = 3 * a.D;
+  const DocView doc = doc_view(a, b);
+  const int L = doc.Lb;                     // rows of this document (packed batches: its length)
+  if (t0 >= L) {                           // nothing to do, but the bias-gradient slab row of this (document, tile) is summed later
+    if (a.bias_slab && threadIdx.x < hd) a.bias_slab[(size_t)(b * ntiles + tile) * ld + h * hd + threadIdx.x] = 0.f;
+    return;
+  }
+  const bf16_t* qbase = reinterpret_cast<const bf16_t*>(a.qkv) + (size_t)doc.base * ld + h * hd;
+  const bf16_t* dcbase = reinterpret_cast<const bf16_t*>(a.dctx) + (size_t)doc.base * a.D + h * hd;
 
   stage_dma<KK>(img, qbase + a.D, ld, t0 - w, TROWS - WROWS + 16 * NKB, L);          // K rows
 
@@ -266,7 +275,7 @@ __global__ __launch_bounds__(256, OCC) void band_mfma_bwd_q_kernel(const BandArg
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     const int i = q0 + 16 * qb + l15;
-    const float* prow = a.probs + ((size_t)(b * L + min(i, L - 1)) * a.heads + h) * a.slots;
+    const float* prow = a.probs + ((size_t)(doc.base + min(i, L - 1)) * a.heads + h) * a.slots;
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -306,7 +315,7 @@ __global__ __launch_bounds__(256, OCC) void band_mfma_bwd_q_kernel(const BandArg
   for (int qb = 0; qb < 2; ++qb) {
     const int i = q0 + 16 * qb + l15;
     if (i < L) {
-      float* dsrow = a.dscores + ((size_t)(b * L + i) * a.heads + h) * a.slots;
+      float* dsrow = a.dscores + ((size_t)(doc.base + i) * a.heads + h) * a.slots;
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -324,7 +333,7 @@ __global__ __launch_bounds__(256, OCC) void band_mfma_bwd_q_kernel(const BandArg
   cv_phase<KK, NKB / 2>(img, lo, hi, coef, lane, o);
   float* red = reinterpret_cast<float*>(img + a.img_bytes);
   float* slab = a.bias_slab ? a.bias_slab + (size_t)(b * ntiles + tile) * ld + h * hd : nullptr;
-  emit_rows<KK>(img, red, reinterpret_cast<bf16_t*>(a.dqkv) + (size_t)b * L * ld + h * hd, ld, q0, L, a.q_scale, o, slab);
+  emit_rows<KK>(img, red, reinterpret_cast<bf16_t*>(a.dqkv) + (size_t)doc.base * ld + h * hd, ld, q0, L, a.q_scale, o, slab);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -368,13 +377,22 @@ __global__ __launch_bounds__(256, OCC) void band_mfma_bwd_kv_kernel(const BandAr
   decode_block(ntiles, a.heads, ntiles * a.heads * a.B, tile, h, b);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
   const int t0 = tile * TROWS, j0 = t0 + WROWS * wave;
-  const int w = a.radius, W = 2 * w + 1, hd = a.hd, ld = 3 * a.D, L = a.L;
-  const bf16_t* qbase = reinterpret_cast<const bf16_t*>(a.qkv) + (size_t)b * L * ld + h * hd;
-  const bf16_t* dcbase = reinterpret_cast<const bf16_t*>(a.dctx) + (size_t)b * L * a.D + h * hd;
+  const int w = a.radius, W = 2 * w + 1, hd = a.hd, ld = 3 * a.D;
+  const DocView doc = doc_view(a, b);
+  const int L = doc.Lb;                     // rows of this document (packed batches: its length)
+  if (t0 >= L) {
+    if (a.bias_slab && threadIdx.x < hd) {
+      float* z = a.bias_slab + (size_t)(b * ntiles + tile) * ld + h * hd + threadIdx.x;
+      z[a.D] = 0.f; z[2 * a.D] = 0.f;
+    }
+    return;
+  }
+  const bf16_t* qbase = reinterpret_cast<const bf16_t*>(a.qkv) + (size_t)doc.base * ld + h * hd;
+  const bf16_t* dcbase = reinterpret_cast<const bf16_t*>(a.dctx) + (size_t)doc.base * a.D + h * hd;
   const size_t xrow = (size_t)a.heads * a.slots;
-  const float* pb = a.probs + ((size_t)b * L * a.heads + h) * a.slots;
-  const float* dsb = a.dscores + ((size_t)b * L * a.heads + h) * a.slots;
-  bf16_t* out = reinterpret_cast<bf16_t*>(a.dqkv) + (size_t)b * L * ld + h * hd;
+  const float* pb = a.probs + ((size_t)doc.base * a.heads + h) * a.slots;
+  const float* dsb = a.dscores + ((size_t)doc.base * a.heads + h) * a.slots;
+  bf16_t* out = reinterpret_cast<bf16_t*>(a.dqkv) + (size_t)doc.base * ld + h * hd;
   const int nrows = TROWS - WROWS + 16 * NKB;
 
   int lo[NS], hi[NS];

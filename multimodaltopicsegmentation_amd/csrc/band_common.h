@@ -10,6 +10,7 @@ struct BandArgs {
   int rs;      // LDS row stride (bytes) of staged q/k/v rows
   int ps;      // LDS row stride (floats) of the probability tile
   float q_scale;
+  const int32_t* row0;  // packed batches: first row of document b (rows of a document are contiguous, only its `lengths[b]` valid rows exist); NULL = padded [B, L]
   float* bias_slab;   // MFMA backward: per-(document, 128-row tile) column sums of dqkv, [B*ceil(L/128)][3D], or NULL
   int img_bytes;      // MFMA kernels: size of the staged-row LDS image
 };
@@ -26,6 +27,13 @@ __device__ __forceinline__ void decode_block(int ntiles, int heads, int nblocks,
   b = bid / (ntiles * heads);
 }
 
+
+// where document b lives: first row and number of rows that exist for it
+struct DocView { int base; int Lb; };
+__device__ __forceinline__ DocView doc_view(const BandArgs& a, int b) {
+  if (a.row0) return DocView{a.row0[b], min(a.lengths[b], a.L)};
+  return DocView{b * a.L, a.L};
+}
 
 // band_attn_mfma.hip: returns MTS_OK after launching, or -1 when the shape is outside what the MFMA kernels cover
 // (the caller then takes the generic kernels).

@@ -51,11 +51,12 @@ __device__ __forceinline__ float bce_elem(float x, float y, float& grad) {
 __global__ __launch_bounds__(256) void tagger_loss_kernel(int kind, int B, int L, int Lt, int n_out, const float* __restrict__ scores,
                                                            const float* __restrict__ targets, const int32_t* __restrict__ lengths,
                                                            float alpha, float gamma, float* __restrict__ loss_out, float* __restrict__ dscores,
-                                                           float* __restrict__ partial) {
+                                                           float* __restrict__ partial, const int32_t* __restrict__ row_src, int n_rows) {
   // gridDim.x > 1: every workgroup recomputes the (cheap) row count, handles an interleaved share of the rows and leaves
   // its partial loss sum in partial[blockIdx.x]; tagger_loss_final_kernel adds them in a fixed order.
+  // packed batches (row_src != NULL): scores/dscores have n_rows rows, row r is sentence row_src[r] = b*L + i (always valid)
   __shared__ float red[16];
-  const int N = B * L;
+  const int N = row_src ? n_rows : B * L;
   constexpr int U = 2;                          // rows per thread per batch: their loads are issued together
   const int step = blockDim.x * U;
   // pass 1: number of rows that are averaged
@@ -66,7 +67,8 @@ __global__ __launch_bounds__(256) void tagger_loss_kernel(int kind, int B, int L
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int r = base + u * blockDim.x;
-        y[u] = (r < N) ? targets[(size_t)(r / L) * Lt + r % L] : -1.f;
+        const int src = (r < N && row_src) ? row_src[r] : r;
+        y[u] = (r < N) ? targets[(size_t)(src / L) * Lt + src % L] : -1.f;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) cnt += (y[u] != -1.f) ? 1.f : 0.f;
@@ -84,7 +86,8 @@ __global__ __launch_bounds__(256) void tagger_loss_kernel(int kind, int B, int L
     for (int u = 0; u < U; ++u) {
       const int r = base + u * blockDim.x;
       const bool in = r < N;
-      const int b = in ? r / L : 0, i = in ? r % L : 0;
+      const int src = (in && row_src) ? row_src[r] : r;
+      const int b = in ? src / L : 0, i = in ? src % L : 0;
       y[u] = in ? targets[(size_t)b * Lt + i] : -1.f;
       len[u] = in ? (lengths ? lengths[b] : L) : 0;
       if (kind == MTS_LOSS_CE) { x0[u] = in ? scores[(size_t)r * 2] : 0.f; x1[u] = in ? scores[(size_t)r * 2 + 1] : 0.f; }
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(256) void tagger_loss_kernel(int kind, int B, int L
     for (int u = 0; u < U; ++u) {
       const int r = base + u * blockDim.x;
       if (r >= N) continue;
-      const int i = r % L;
+      const int i = (row_src ? row_src[r] : r) % L;
       if (kind == MTS_LOSS_CE) {
         float g0 = 0.f, g1 = 0.f;
         if (y[u] != -1.f) {
@@ -153,16 +156,17 @@ extern "C" size_t mts_tagger_loss_workspace(int B, int L) { return (size_t)std::
 
 extern "C" int mts_tagger_loss(void* stream, int loss_kind, int B, int L, int Lt, int n_out, const float* scores, const float* targets,
                                const int32_t* lengths, float alpha, float gamma, float* loss_out, float* dscores, void* workspace,
-                               size_t workspace_bytes) {
+                               size_t workspace_bytes, const int32_t* row_src, int n_rows) {
   MTS_CHECK_ARG(B > 0 && L > 0 && Lt >= L && scores && targets && loss_out, "mts_tagger_loss: bad arguments");
   MTS_CHECK_ARG(loss_kind == MTS_LOSS_CE || loss_kind == MTS_LOSS_BCE || loss_kind == MTS_LOSS_FOCAL,
                 "Choose one of CrossEntropy or BinaryCrossEntropy as loss function");   /* models/CRF.py:312 */
   MTS_CHECK_ARG((loss_kind == MTS_LOSS_CE) ? n_out == 2 : n_out == 1, "mts_tagger_loss: n_out=%d does not match the loss kind", n_out);
   // 256 threads x 8 rows per workgroup; one workgroup (no workspace needed) up to 2048 rows
-  const int nblocks = (int)std::min<size_t>(ceil_div(B * L, 256 * 2), workspace ? workspace_bytes / sizeof(float) : 1);
+  MTS_CHECK_ARG(!row_src || (n_rows > 0 && n_rows <= B * L), "mts_tagger_loss: packed form needs 0 < n_rows <= B*L");
+  const int nblocks = (int)std::min<size_t>(ceil_div(row_src ? n_rows : B * L, 256 * 2), workspace ? workspace_bytes / sizeof(float) : 1);
   const int grid = std::max(1, std::min(nblocks, 1024));
   hipLaunchKernelGGL(tagger_loss_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, loss_kind, B, L, Lt, n_out, scores, targets, lengths,
-                     alpha, gamma, loss_out, dscores, (float*)workspace);
+                     alpha, gamma, loss_out, dscores, (float*)workspace, row_src, n_rows);
   if (grid > 1) hipLaunchKernelGGL(tagger_loss_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, grid, (const float*)workspace, loss_out);
   MTS_LAUNCH_CHECK("mts_tagger_loss");
   return MTS_OK;

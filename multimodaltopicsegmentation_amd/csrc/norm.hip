@@ -60,14 +60,17 @@ __global__ __launch_bounds__(64 * ROW_WAVES) void ln_fwd_kernel(
     const void* __restrict__ xin, const float* __restrict__ pos, int pos_offset, int L, const float* __restrict__ type0,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int rows, int D,
     T* __restrict__ y, T* __restrict__ pre, float* __restrict__ mean_out, float* __restrict__ rstd_out,
-    const float* __restrict__ head_w, const float* __restrict__ head_b, int n_out, float* __restrict__ scores) {
+    const float* __restrict__ head_w, const float* __restrict__ head_b, int n_out, float* __restrict__ scores,
+    const int32_t* __restrict__ row_src) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * ROW_WAVES + (threadIdx.x >> 6);
   if (row >= rows) return;
   float x[NV][4];
   if constexpr (EMBED) {
-    const float* xr = reinterpret_cast<const float*>(xin) + (size_t)row * D;
-    const float* pr = pos + (size_t)(pos_offset + row % L) * D;
+    // packed batches: output row `row` is sentence row_src[row] = b*L + i of the padded batch (position = i)
+    const int src = row_src ? row_src[row] : row;
+    const float* xr = reinterpret_cast<const float*>(xin) + (size_t)src * D;
+    const float* pr = pos + (size_t)(pos_offset + src % L) * D;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int e = 4 * (lane + 64 * i);
@@ -417,13 +420,24 @@ int mts_slab_reduce_rows(hipStream_t st, const float* partial, int nblocks, int 
 
 // dpos[pos_offset+i,:] += sum_b dpre[b,i,:]
 template <typename T>
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ dpre, int B, int L, int D, float* __restrict__ dpos, int pos_offset) {
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ dpre, int B, int L, int D, float* __restrict__ dpos, int pos_offset,
+                                                        const int32_t* __restrict__ row0, const int32_t* __restrict__ lengths) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int per_row = D / 4;
   if (idx >= (size_t)L * per_row) return;
   const int i = (int)(idx / per_row), e = 4 * (int)(idx % per_row);
   float s[4] = {0.f, 0.f, 0.f, 0.f};
   int b = 0;
+  if (row0) {                                // packed rows: document b owns rows row0[b] .. row0[b] + lengths[b] - 1
+    for (; b < B; ++b) {
+      if (i < lengths[b]) {
+        float v[4];
+        load4<T>(dpre + ((size_t)row0[b] + i) * D + e, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] += v[j];
+      }
+    }
+  }
   for (; b + 7 < B; b += 8) {            // 8 documents' loads in flight per lane
     float v[8][4];
 #pragma unroll
@@ -483,14 +497,14 @@ template <typename F> static inline void dispatch_nv8(int nv, F&& f) {   // kern
 template <typename T, bool EMBED>
 static int ln_fwd_launch(hipStream_t st, const void* x, const float* pos, int pos_offset, int L, const float* type0, const float* gamma,
                          const float* beta, float eps, int rows, int D, void* y, void* pre, float* mean, float* rstd,
-                         const float* head_w, const float* head_b, int n_out, float* scores) {
+                         const float* head_w, const float* head_b, int n_out, float* scores, const int32_t* row_src = nullptr) {
   const int nv = pick_nv(D);
   MTS_UNSUPPORTED(nv > 0 && D % 4 == 0, "layernorm: D=%d must be a multiple of 4 and <= 4096", D);
   dim3 grid(ceil_div(rows, ROW_WAVES)), block(64 * ROW_WAVES);
   dispatch_nv(nv, [&](auto nvc) {
     constexpr int NV = decltype(nvc)::value;
     hipLaunchKernelGGL((ln_fwd_kernel<T, NV, EMBED>), grid, block, 0, st, x, pos, pos_offset, L, type0, gamma, beta, eps, rows, D, (T*)y,
-                       (T*)pre, mean, rstd, head_w, head_b, n_out, scores);
+                       (T*)pre, mean, rstd, head_w, head_b, n_out, scores, row_src);
   });
   MTS_LAUNCH_CHECK("layernorm_fwd");
   return MTS_OK;
@@ -498,14 +512,16 @@ static int ln_fwd_launch(hipStream_t st, const void* x, const float* pos, int po
 
 extern "C" int mts_embed_layernorm_fwd(void* stream, int dtype, int B, int L, int D, const float* x, const float* pos, int pos_offset,
                                        const float* type0, const float* gamma, const float* beta, float eps, void* y, void* pre,
-                                       float* mean, float* rstd) {
+                                       float* mean, float* rstd, const int32_t* row_src, int n_rows) {
   MTS_CHECK_ARG(B > 0 && L > 0 && D > 0 && x && pos && type0 && gamma && beta && y, "mts_embed_layernorm_fwd: bad arguments");
+  MTS_CHECK_ARG(!row_src || (n_rows > 0 && n_rows <= B * L), "mts_embed_layernorm_fwd: packed form needs 0 < n_rows <= B*L");
+  const int rows = row_src ? n_rows : B * L;
   if (dtype == MTS_F32)
-    return ln_fwd_launch<float, true>((hipStream_t)stream, x, pos, pos_offset, L, type0, gamma, beta, eps, B * L, D, y, pre, mean, rstd,
-                                      nullptr, nullptr, 0, nullptr);
+    return ln_fwd_launch<float, true>((hipStream_t)stream, x, pos, pos_offset, L, type0, gamma, beta, eps, rows, D, y, pre, mean, rstd,
+                                      nullptr, nullptr, 0, nullptr, row_src);
   if (dtype == MTS_BF16)
-    return ln_fwd_launch<bf16_t, true>((hipStream_t)stream, x, pos, pos_offset, L, type0, gamma, beta, eps, B * L, D, y, pre, mean, rstd,
-                                       nullptr, nullptr, 0, nullptr);
+    return ln_fwd_launch<bf16_t, true>((hipStream_t)stream, x, pos, pos_offset, L, type0, gamma, beta, eps, rows, D, y, pre, mean, rstd,
+                                       nullptr, nullptr, 0, nullptr, row_src);
   mts_set_error("mts_embed_layernorm_fwd: bad dtype %d", dtype);
   return MTS_ERR_INVALID;
 }
@@ -558,12 +574,14 @@ extern "C" int mts_layernorm_bwd(void* stream, int dtype, int rows, int D, const
   return MTS_ERR_INVALID;
 }
 
-extern "C" int mts_embed_bwd(void* stream, int dtype, int B, int L, int D, const void* dpre, float* dpos, int pos_offset) {
+extern "C" int mts_embed_bwd(void* stream, int dtype, int B, int L, int D, const void* dpre, float* dpos, int pos_offset, const int32_t* row0,
+                             const int32_t* lengths) {
   MTS_CHECK_ARG(B > 0 && L > 0 && D > 0 && D % 4 == 0 && dpre && dpos, "mts_embed_bwd: bad arguments");
+  MTS_CHECK_ARG(!row0 || lengths, "mts_embed_bwd: packed form needs lengths");
   hipStream_t st = (hipStream_t)stream;
   const int blocks = (int)(((size_t)L * (D / 4) + 255) / 256);
-  if (dtype == MTS_F32) hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dpre, B, L, D, dpos, pos_offset);
-  else if (dtype == MTS_BF16) hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dpre, B, L, D, dpos, pos_offset);
+  if (dtype == MTS_F32) hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dpre, B, L, D, dpos, pos_offset, row0, lengths);
+  else if (dtype == MTS_BF16) hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dpre, B, L, D, dpos, pos_offset, row0, lengths);
   else { mts_set_error("mts_embed_bwd: bad dtype %d", dtype); return MTS_ERR_INVALID; }
   MTS_LAUNCH_CHECK("mts_embed_bwd");
   return MTS_OK;

@@ -121,10 +121,12 @@ def cast(src, dst):
     return dst
 
 
-def embed_layernorm_fwd(x, pos, pos_offset, type0, gamma, beta, eps, y, pre, mean, rstd):
+def embed_layernorm_fwd(x, pos, pos_offset, type0, gamma, beta, eps, y, pre, mean, rstd, row_src=None):
+    """row_src (int32 [n_rows], optional): packed batch -- output row r is sentence row_src[r] = b*L + i of x."""
     B, Lq, D = x.shape
     check(lib.mts_embed_layernorm_fwd(stream_ptr(), dtype_code(y.dtype), B, Lq, D, ptr(x), ptr(pos), pos_offset, ptr(type0),
-                                      ptr(gamma), ptr(beta), eps, ptr(y), ptr(pre), ptr(mean), ptr(rstd)))
+                                      ptr(gamma), ptr(beta), eps, ptr(y), ptr(pre), ptr(mean), ptr(rstd), ptr(row_src),
+                                      row_src.numel() if row_src is not None else 0))
 
 
 def layernorm_fwd(x, gamma, beta, eps, y, mean, rstd, head_w=None, head_b=None, scores=None):
@@ -142,9 +144,10 @@ def layernorm_bwd(x, dy, gamma, mean, rstd, dx, dgamma, dbeta, dxsum=None, dlogi
                                 ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(dxsum), ptr(ws)))
 
 
-def embed_bwd(dpre, B, Lq, dpos, pos_offset):
+def embed_bwd(dpre, B, Lq, dpos, pos_offset, row0=None, lengths=None):
     D = dpre.shape[-1]
-    check(lib.mts_embed_bwd(stream_ptr(), dtype_code(dpre.dtype), B, Lq, D, ptr(dpre), ptr(dpos), pos_offset))
+    check(lib.mts_embed_bwd(stream_ptr(), dtype_code(dpre.dtype), B, Lq, D, ptr(dpre), ptr(dpos), pos_offset, ptr(row0),
+                            ptr(lengths) if row0 is not None else None))
 
 
 def gelu_bwd(u, dy):
@@ -155,26 +158,34 @@ def band_slots(radius):
     return lib.mts_band_slots(radius)
 
 
-def band_attn_fwd(qkv, lengths, B, Lq, D, heads, radius, ctx, probs):
+def band_attn_fwd(qkv, lengths, B, Lq, D, heads, radius, ctx, probs, row0=None):
+    """row0 (int32 [B], optional): packed batch -- document b owns rows row0[b] .. row0[b] + lengths[b] - 1 of qkv / ctx / probs."""
     with _timed(('band_fwd', B, Lq, D, heads, radius)):
-        check(lib.mts_band_attn_fwd(stream_ptr(), dtype_code(qkv.dtype), B, Lq, D, heads, radius, ptr(qkv), ptr(lengths), ptr(ctx), ptr(probs)))
+        check(lib.mts_band_attn_fwd(stream_ptr(), dtype_code(qkv.dtype), B, Lq, D, heads, radius, ptr(qkv), ptr(lengths), ptr(ctx), ptr(probs),
+                                    ptr(row0)))
 
 
-def band_attn_bwd(qkv, lengths, probs, dctx, B, Lq, D, heads, radius, dqkv, dscores, dbias=None):
+def band_attn_bwd(qkv, lengths, probs, dctx, B, Lq, D, heads, radius, dqkv, dscores, dbias=None, row0=None):
     """dbias (fp32 [3D], optional): column sums of dqkv = q/k/v bias gradients, fused into the kernels' output stage."""
     q_scale = 1.0 / math.sqrt(D // heads)
     ws = _scratch(lib.mts_band_attn_bwd_workspace(B, Lq, D), qkv.device, 'band_bwd') if dbias is not None else None
     with _timed(('band_bwd', B, Lq, D, heads, radius)):
         check(lib.mts_band_attn_bwd(stream_ptr(), dtype_code(qkv.dtype), B, Lq, D, heads, radius, q_scale, ptr(qkv), ptr(lengths),
-                                    ptr(probs), ptr(dctx), ptr(dqkv), ptr(dscores), ptr(dbias), ptr(ws)))
+                                    ptr(probs), ptr(dctx), ptr(dqkv), ptr(dscores), ptr(dbias), ptr(ws), ptr(row0),
+                                    qkv.shape[0] if row0 is not None else 0))
 
 
-def tagger_loss(kind, scores, targets, lengths, alpha, gamma, loss_out, dscores):
-    B, Lq, n_out = scores.shape
+def tagger_loss(kind, scores, targets, lengths, alpha, gamma, loss_out, dscores, row_src=None, batch_shape=None):
+    """scores [B, L, n_out]; or, for a packed batch, [n_rows, n_out] with row_src (int32 [n_rows]) and batch_shape = (B, L)."""
+    if row_src is None:
+        B, Lq, n_out = scores.shape
+    else:
+        (B, Lq), n_out = batch_shape, scores.shape[-1]
     nb = lib.mts_tagger_loss_workspace(B, Lq)
     ws = _scratch(nb, scores.device, 'loss')
     check(lib.mts_tagger_loss(stream_ptr(), kind, B, Lq, targets.shape[1], n_out, ptr(scores), ptr(targets), ptr(lengths),
-                              float(alpha), float(gamma), ptr(loss_out), ptr(dscores), ptr(ws), nb))
+                              float(alpha), float(gamma), ptr(loss_out), ptr(dscores), ptr(ws), nb, ptr(row_src),
+                              row_src.numel() if row_src is not None else 0))
 
 
 def greedy_decode(scores, lengths, threshold, tags_out):

@@ -253,27 +253,29 @@ class Transformer_segmenter(_TaggerBase):
             del state_dict[k]
 
     # ---- native forward / backward ------------------------------------------------------------------
-    def _forward_native(self, xs, lengths_i32, want_grad_state=True):
+    def _forward_native(self, xs, lengths_i32, want_grad_state=True, pack=None):
+        """pack = {'row_src', 'row0', 'n'} (see _pack_plan): activations hold only the valid sentences."""
         dt, dev = self.compute_dtype, xs.device
         B, Lq, D = xs.shape
         if D != self.embedding_dim:
             raise ValueError(f'expected input dim {self.embedding_dim}, got {D}')
         if Lq + 2 > self.max_pos:
             raise ValueError(f'sequence length {Lq} exceeds max_position_embeddings-2 = {self.max_pos - 2}')
-        N, F, H = B * Lq, self.hidden_dim, self.nheads
+        N, F, H = (pack['n'] if pack else B * Lq), self.hidden_dim, self.nheads
+        row_src, row0 = (pack['row_src'], pack['row0']) if pack else (None, None)
         ws, lay = self._ws, self._layout
         wf = self._weights()                  # compute-dtype mirror (GEMM operands)
         pf = self._flat                       # fp32 masters (biases, LayerNorm, embeddings, head)
         x = xs.contiguous().to(torch.float32)
         e = 'model.model.embeddings.'
-        st = {'B': B, 'L': Lq, 'N': N, 'lengths': lengths_i32, 'layers': []}
+        st = {'B': B, 'L': Lq, 'N': N, 'lengths': lengths_i32, 'layers': [], 'pack': pack}
         h = ws.get('h0', N, D, dt, dev)
         pre0 = ws.get('pre0', N, D, dt, dev)
         mean0 = ws.get('mean0', N, 1, torch.float32, dev)
         rstd0 = ws.get('rstd0', N, 1, torch.float32, dev)
         ops.embed_layernorm_fwd(x, lay.view(pf, e + 'position_embeddings.weight'), 2,
                                 lay.view(pf, e + 'token_type_embeddings.weight')[0], lay.view(pf, e + 'LayerNorm.weight'),
-                                lay.view(pf, e + 'LayerNorm.bias'), self.ln_eps, h, pre0, mean0, rstd0)
+                                lay.view(pf, e + 'LayerNorm.bias'), self.ln_eps, h, pre0, mean0, rstd0, row_src=row_src)
         st.update(pre0=pre0, mean0=mean0, rstd0=rstd0)
         scores = ws.get('scores', N, self.n_out, torch.float32, dev)
         scale = 1.0 / math.sqrt(D // H)
@@ -287,7 +289,7 @@ class Transformer_segmenter(_TaggerBase):
             ops.linear_fwd(h, wqkv, bqkv, qkv, colscale=scale, ncols_scaled=D)
             ctx = ws.get(f'ctx{li}', N, D, dt, dev)
             probs = ws.get(f'probs{li}', N, H * slots, torch.float32, dev)
-            ops.band_attn_fwd(qkv, lengths_i32, B, Lq, D, H, radius, ctx, probs)
+            ops.band_attn_fwd(qkv, lengths_i32, B, Lq, D, H, radius, ctx, probs, row0=row0)
             s1 = ws.get(f's1_{li}', N, D, dt, dev)
             ops.linear_fwd(ctx, self._w(wf, lp + 'attention.output.dense.weight'), self._w(pf, lp + 'attention.output.dense.bias'),
                            s1, residual=h)
@@ -313,7 +315,7 @@ class Transformer_segmenter(_TaggerBase):
             st['layers'].append(dict(hin=h, qkv=qkv, ctx=ctx, probs=probs, s1=s1, a1=a1, mean1=mean1, rstd1=rstd1, u=u, f=f,
                                      s2=s2, hout=hout, mean2=mean2, rstd2=rstd2, radius=radius, slots=slots))
             h = hout
-        st['scores'] = scores.view(B, Lq, self.n_out)
+        st['scores'] = scores if pack else scores.view(B, Lq, self.n_out)
         st['hidden'] = h
         return st
 
@@ -366,7 +368,8 @@ class Transformer_segmenter(_TaggerBase):
             dsc = ws.get('dsc', N, H * S['slots'], torch.float32, dev)
             a_ = lp + 'attention.self.'
             off, n = lay.span(a_ + 'query.bias', a_ + 'value.bias')
-            ops.band_attn_bwd(S['qkv'], st['lengths'], S['probs'], dctx, B, Lq, D, H, S['radius'], dqkv, dsc, dbias=g[off:off + n])
+            ops.band_attn_bwd(S['qkv'], st['lengths'], S['probs'], dctx, B, Lq, D, H, S['radius'], dqkv, dsc, dbias=g[off:off + n],
+                              row0=st['pack']['row0'] if st['pack'] else None)
             off, n = lay.span(a_ + 'query.weight', a_ + 'value.weight')
             ops.linear_wgrad(dqkv, S['hin'], g[off:off + n].view(3 * D, D))
             self._grads_ready(off, lay.entries[lp + 'attention.output.dense.weight'][0])    # q/k/v weights + biases
@@ -380,25 +383,53 @@ class Transformer_segmenter(_TaggerBase):
         ops.layernorm_bwd(st['pre0'], dh, self._w(pf, e + 'LayerNorm.weight'), st['mean0'], st['rstd0'], dpre,
                           G(e + 'LayerNorm.weight'), G(e + 'LayerNorm.bias'), dxsum=G(e + 'token_type_embeddings.weight')[0])
         G(e + 'position_embeddings.weight').zero_()
-        ops.embed_bwd(dpre, B, Lq, G(e + 'position_embeddings.weight'), 2)
+        ops.embed_bwd(dpre, B, Lq, G(e + 'position_embeddings.weight'), 2, row0=st['pack']['row0'] if st['pack'] else None,
+                      lengths=st['lengths'])
         # embeddings: only the position rows a batch of this length can touch, then type row + LayerNorm
         D_ = self.embedding_dim
         p0 = lay.entries[e + 'position_embeddings.weight'][0]
         self._grads_ready(p0 + 2 * D_, p0 + (Lq + 2) * D_)
         self._grads_ready(lay.entries[e + 'token_type_embeddings.weight'][0], lay.entries['model.model.encoder.layer.0.attention.self.query.weight'][0])
 
+    # ---- packed batches ---------------------------------------------------------------------------------
+    pack_rows = 'auto'     # training path: 'auto' packs when >= 10 % of the B*L rows are padding; True / False force it
+
+    def _pack_plan(self, lengths, B, Lq, dev):
+        """The reference pads every Transformer batch to 3600 sentences (train_fit.py:104-106; real documents: median 359)
+        and pushes all of them through the encoder.  Padded rows never reach a valid row (masked as keys) nor the loss, so
+        the training path keeps only the valid sentences, document after document: row_src[r] = b*L + i, row0[b] = first
+        packed row of document b.  Same loss and gradients up to fp32 summation order."""
+        if self.pack_rows is False or lengths is None:
+            return None
+        lens = [max(0, min(int(v), Lq)) for v in (lengths.tolist() if hasattr(lengths, 'tolist') else lengths)]
+        n = sum(lens)
+        if n == 0 or (self.pack_rows == 'auto' and n > 0.9 * B * Lq):
+            return None
+        key = (tuple(lens), Lq, str(dev))
+        if getattr(self, '_pack_key', None) != key:
+            import numpy as np
+            row0 = np.zeros(B, dtype=np.int32)
+            row0[1:] = np.cumsum(lens[:-1], dtype=np.int64)
+            row_src = np.concatenate([b * Lq + np.arange(n_b, dtype=np.int32) for b, n_b in enumerate(lens)]).astype(np.int32)
+            self._pack_val = {'row_src': torch.from_numpy(row_src).to(dev), 'row0': torch.from_numpy(row0).to(dev), 'n': n}
+            self._pack_key = key
+        return self._pack_val
+
     # ---- public API ------------------------------------------------------------------------------------
     def loss_and_grad(self, xs, lengths, tags, want_grad=True):
-        """Native forward(+backward): returns (loss 0-d fp32 tensor, scores [B,L,n_out]); gradients land in grad_flat."""
+        """Native forward(+backward): returns (loss 0-d fp32 tensor, scores [B,L,n_out] -- or [n_valid, n_out] when the batch
+        was packed, see _pack_plan); gradients land in grad_flat."""
         L.require_gpu()
         dev = xs.device
         B, Lq, _ = xs.shape
         li32 = self._prep_lengths(lengths, B, Lq, dev)
-        st = self._forward_native(xs, li32)
+        pack = self._pack_plan(lengths, B, Lq, dev)
+        st = self._forward_native(xs, li32, pack=pack)
         tg = tags.to(device=dev, dtype=torch.float32).contiguous()
         loss_out = torch.empty(2, dtype=torch.float32, device=dev)
         dsc = self._ws.get('dscores', st['N'], self.n_out, torch.float32, dev) if want_grad else None
-        ops.tagger_loss(self.loss_kind, st['scores'], tg, li32, self.alpha, self.gamma, loss_out, dsc)
+        ops.tagger_loss(self.loss_kind, st['scores'], tg, li32, self.alpha, self.gamma, loss_out, dsc,
+                        row_src=pack['row_src'] if pack else None, batch_shape=(B, Lq))
         if want_grad:
             self._backward_native(st, dsc)
         return loss_out[0], st['scores']

@@ -41,7 +41,7 @@ def test_error_codes_map_to_reference_exceptions():
     import pytest
     from multimodaltopicsegmentation_amd import _lib as L
     # argument validation happens before any device work, so this is safe without a GPU
-    rc = L.lib.mts_tagger_loss(None, 9, 1, 1, 1, 1, None, None, None, 0.9, 2.0, None, None, None, 0)
+    rc = L.lib.mts_tagger_loss(None, 9, 1, 1, 1, 1, None, None, None, 0.9, 2.0, None, None, None, 0, None, 0)
     assert rc == 1
     with pytest.raises(ValueError):
         L.check(rc)

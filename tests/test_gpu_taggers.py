@@ -406,3 +406,36 @@ def test_late_fusion_1024_768_against_oracle(dtype):
         a, r = prm.grad.detach().cpu().double(), ref_g[n]
         scale = max(float(r.abs().max()), 1e-9)
         assert float((a - r).abs().max()) < (2e-3 if f32 else 0.12) * scale + (1e-7 if f32 else 2e-4), n
+
+
+# ------------------------------------------------------------------------------------------------ packed (un-padded) training path
+@pytest.mark.parametrize('dtype,D,heads,window,NL', [('fp32', 64, 4, 8, 2), ('bf16', 64, 2, 30, 1), ('bf16', 448, 2, 30, 1)])
+def test_packed_batch_gives_the_same_loss_and_gradients(dtype, D, heads, window, NL):
+    """Training keeps only the valid sentences (the reference pads to 3600 and encodes the padding too): loss and every
+    gradient must equal the padded run's -- fp32 to summation-order accuracy, bf16 within its rounding."""
+    from multimodaltopicsegmentation_amd.taggers import Transformer_segmenter
+    B, L = 5, 300
+    lengths = torch.tensor([300, 131, 1, 47, 260])
+    m = Transformer_segmenter(2, D, 32, num_layers=NL, nheads=heads, loss_fn='FocalLoss', window_size=window, compute_dtype=dtype, seed=31).to(DEV)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, L, D, generator=g)
+    y = torch.full((B, L), -1.0)
+    for b, n in enumerate(lengths.tolist()):
+        x[b, n:] = 0.0
+        y[b, :n] = (torch.rand(n, generator=g) < 0.15).float()
+    x, y = x.to(DEV), y.to(DEV)
+    m.pack_rows = False
+    loss_pad, _ = m.loss_and_grad(x, lengths, y, True)
+    g_pad = m.grad_flat().clone()
+    loss_pad = loss_pad.item()
+    m.pack_rows = True
+    loss_pk, sc = m.loss_and_grad(x, lengths, y, True)
+    g_pk = m.grad_flat().clone()
+    assert sc.shape == (int(lengths.sum()), 1)
+    f32 = dtype == 'fp32'
+    assert abs(loss_pk.item() - loss_pad) < (1e-6 if f32 else 2e-3) * max(1.0, abs(loss_pad))
+    scale = float(g_pad.abs().max())
+    err = float((g_pk - g_pad).abs().max())
+    assert err < (2e-5 if f32 else 2e-2) * scale, (err, scale)
+    m.pack_rows = 'auto'
+    assert m._pack_plan(lengths, B, L, x.device) is not None and m._pack_plan(torch.full((B,), L), B, L, x.device) is None
