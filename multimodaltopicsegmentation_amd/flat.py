@@ -16,9 +16,44 @@ import torch.nn as nn
 ALIGN = 64  # elements (256 B): every group starts on a 256-byte boundary -> 16-byte vector access everywhere
 
 
+def round_up(n, m):
+    return (int(n) + m - 1) // m * m
+
+
+# ---- padded storage ---------------------------------------------------------------------------------
+# The kernels want feature dimensions that are multiples of 8 (16-byte bf16 vectors, MFMA k-steps); the reference's
+# DEFAULT hidden size is 25 (train_fit.py:689).  Such a dimension is stored padded: a pad spec is a list of
+# (axis, blocks, n, n_pad) -- along `axis` the logical tensor is `blocks` blocks of n entries (e.g. the 4 LSTM gates of H
+# units), each stored as n_pad entries with zeros behind the n real ones.  Padded units are inert by construction (zero
+# weights and biases -> zero activations and zero gradients, so Adam/SGD leave them at zero); parameters are the padded
+# storage tensors, and state_dict()/load_state_dict() convert to/from the reference's logical shapes.
+def pad_blocks(t, spec):
+    for axis, blocks, n, n_pad in spec:
+        shp = list(t.shape)
+        assert shp[axis] == blocks * n, (shp, spec)
+        t = t.reshape(shp[:axis] + [blocks, n] + shp[axis + 1:])
+        pad_shape = list(t.shape)
+        pad_shape[axis + 1] = n_pad - n
+        t = torch.cat([t, t.new_zeros(pad_shape)], dim=axis + 1)
+        t = t.reshape(shp[:axis] + [blocks * n_pad] + shp[axis + 1:])
+    return t
+
+
+def unpad_blocks(t, spec):
+    for axis, blocks, n, n_pad in spec:
+        shp = list(t.shape)
+        assert shp[axis] == blocks * n_pad, (shp, spec)
+        t = t.reshape(shp[:axis] + [blocks, n_pad] + shp[axis + 1:])
+        t = t.narrow(axis + 1, 0, n)
+        t = t.reshape(shp[:axis] + [blocks * n] + shp[axis + 1:])
+    return t
+
+
 class FlatLayout:
-    def __init__(self, groups):
-        """groups: list of lists of (name, shape); tensors of a group are contiguous, groups are ALIGN-aligned."""
+    def __init__(self, groups, pads=None):
+        """groups: list of lists of (name, STORAGE shape); tensors of a group are contiguous, groups are ALIGN-aligned.
+        pads: {name: pad spec} for tensors whose storage shape is a padded form of the reference's shape."""
+        self.pads = dict(pads or {})
         self.entries = OrderedDict()   # name -> (offset, shape)
         self.group_spans = []          # (offset, numel) per group
         off = 0
@@ -68,8 +103,8 @@ class FlatModule(nn.Module):
     def _init_flat(self, layout, init_values):
         self._layout = layout
         flat = torch.zeros(layout.numel, dtype=torch.float32)
-        for name, val in init_values.items():
-            layout.view(flat, name).copy_(val)
+        for name, val in init_values.items():                      # init values come in the reference's (logical) shapes
+            layout.view(flat, name).copy_(pad_blocks(val, layout.pads[name]) if name in layout.pads else val)
         self._flat = flat
         self._grad_flat = None
         self._flat_params = OrderedDict()
@@ -77,6 +112,28 @@ class FlatModule(nn.Module):
             p = nn.Parameter(layout.view(flat, name))
             self._flat_params[name] = p
             register_nested(self, name, p)
+        if layout.pads:
+            self._register_state_dict_hook(FlatModule._unpad_state_dict)
+            self._register_load_state_dict_pre_hook(self._pad_incoming_state_dict)
+
+    @staticmethod
+    def _unpad_state_dict(module, state_dict, prefix, local_metadata):
+        for name, spec in module._layout.pads.items():
+            k = prefix + name
+            if k in state_dict:
+                state_dict[k] = unpad_blocks(state_dict[k], spec).clone()
+        return state_dict
+
+    def _pad_incoming_state_dict(self, state_dict, prefix, *args):
+        for name, spec in self._layout.pads.items():
+            k = prefix + name
+            if k in state_dict and tuple(state_dict[k].shape) != self._layout.entries[name][1]:
+                state_dict[k] = pad_blocks(state_dict[k], spec)
+
+    def logical_view(self, tensor_by_name, name):
+        """The reference-shaped view of a (padded) parameter / gradient tensor."""
+        t = tensor_by_name[name]
+        return unpad_blocks(t, self._layout.pads[name]) if name in self._layout.pads else t
 
     def _apply(self, fn, recurse=True):
         out = super()._apply(fn, recurse)

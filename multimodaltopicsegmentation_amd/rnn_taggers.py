@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import ops
-from .flat import FlatLayout
+from .flat import FlatLayout, round_up
 from .taggers import _TaggerBase, _linear_init, _xavier_uniform, LOSS_KINDS
 
 IMPOSSIBLE = -1e4   # models/CRF.py:95
@@ -20,42 +20,61 @@ IMPOSSIBLE = -1e4   # models/CRF.py:95
 def _rnn_groups(prefix, D, H, num_layers, gen):
     """Parameter groups + Keras-style init of ``RNN._reinitialize`` (NeuralArchitectures.py:58-79): xavier_uniform
     W_ih, orthogonal W_hh, zero biases with the forget-gate slice of bias_ih set to 1.  The two directions of a
-    layer are adjacent so that one [8H, Din] GEMM projects both."""
-    groups, init = [], {}
+    layer are adjacent so that one [8H, Din] GEMM projects both.
+
+    Returns (groups of STORAGE shapes, init values in the reference's shapes, pad specs): hidden size and input width are
+    stored rounded up to a multiple of 8 (the reference's default hidden size is 25); see flat.py "padded storage"."""
+    Hp, Dp = round_up(H, 8), round_up(D, 8)
+    groups, init, pads = [], {}, {}
+    gate_rows = [(0, 4, H, Hp)] if Hp != H else []
     for k in range(num_layers):
-        din = D if k == 0 else 2 * H
+        din, din_p = (D, Dp) if k == 0 else (2 * H, 2 * Hp)
+        col = ([(1, 1, D, Dp)] if Dp != D else []) if k == 0 else ([(1, 2, H, Hp)] if Hp != H else [])
         g = []
         for sfx in ('', '_reverse'):
             n = f'{prefix}rnn.weight_ih_l{k}{sfx}'
-            g.append((n, (4 * H, din)))
+            g.append((n, (4 * Hp, din_p)))
             init[n] = _xavier_uniform((4 * H, din), gen)
+            if gate_rows or col:
+                pads[n] = gate_rows + col
         groups.append(g)
         g = []
         for sfx in ('', '_reverse'):
             n = f'{prefix}rnn.weight_hh_l{k}{sfx}'
-            g.append((n, (4 * H, H)))
+            g.append((n, (4 * Hp, Hp)))
             w = torch.empty(4 * H, H)
             nn.init.orthogonal_(w, generator=gen)
             init[n] = w
+            if gate_rows:
+                pads[n] = gate_rows + [(1, 1, H, Hp)]
         groups.append(g)
         for kind in ('bias_ih', 'bias_hh'):
             g = []
             for sfx in ('', '_reverse'):
                 n = f'{prefix}rnn.{kind}_l{k}{sfx}'
-                g.append((n, (4 * H,)))
+                g.append((n, (4 * Hp,)))
                 b = torch.zeros(4 * H)
                 if kind == 'bias_ih':
                     b[H:2 * H] = 1.0
                 init[n] = b
+                if gate_rows:
+                    pads[n] = gate_rows
             groups.append(g)
-    return groups, init
+    return groups, init, pads
+
+
+def _head_pad(H, nblocks):
+    """Pad spec of a head weight [n_out, nblocks*H] reading nblocks concatenated hidden vectors."""
+    Hp = round_up(H, 8)
+    return [(1, nblocks, H, Hp)] if Hp != H else None
 
 
 class _RnnStack:
     """Native forward/backward of one ``RNN`` (bidirectional multi-layer LSTM) living inside a flat-parameter model."""
 
     def __init__(self, owner, prefix, D, H, num_layers, tag):
-        self.o, self.prefix, self.D, self.H, self.nl, self.tag = owner, prefix, D, H, num_layers, tag
+        """D, H: the reference's sizes; the kernels run on the padded ones (multiples of 8, padded units inert)."""
+        self.o, self.prefix, self.D, self.H, self.nl, self.tag = owner, prefix, round_up(D, 8), round_up(H, 8), num_layers, tag
 
     def _names(self, kind, k):
         return f'{self.prefix}rnn.{kind}_l{k}', f'{self.prefix}rnn.{kind}_l{k}_reverse'
@@ -129,6 +148,8 @@ class _RnnTaggerBase(_TaggerBase):
 
     def _to_act(self, x):
         x2 = x.reshape(-1, x.shape[-1])
+        if x2.shape[1] % 8:                                           # e.g. 768 + 2 timing features: zero columns up to a multiple of 8
+            x2 = torch.nn.functional.pad(x2.to(torch.float32), (0, round_up(x2.shape[1], 8) - x2.shape[1]))
         if self.compute_dtype == torch.float32:
             return x2.to(torch.float32).contiguous()
         out = self._ws.get('xin_' + str(x2.shape[1]), x2.shape[0], x2.shape[1], torch.bfloat16, x.device)
@@ -148,11 +169,14 @@ class BiLSTM(_RnnTaggerBase):
         self.embedding_dim, self.hidden_dim, self.tagset_size, self.num_layers = embedding_dim, hidden_dim, tagset_size, num_layers
         self.n_out = tagset_size if loss_fn == 'CrossEntropy' else 1
         gen = torch.Generator().manual_seed(torch.initial_seed() if seed is None else seed)
-        groups, init = _rnn_groups('model.', embedding_dim, hidden_dim, num_layers, gen)
+        groups, init, pads = _rnn_groups('model.', embedding_dim, hidden_dim, num_layers, gen)
+        self._hp = round_up(hidden_dim, 8)
         cw, cb = _linear_init(self.n_out, 2 * hidden_dim, gen)
-        groups.append([('classification.weight', (self.n_out, 2 * hidden_dim)), ('classification.bias', (self.n_out,))])
+        groups.append([('classification.weight', (self.n_out, 2 * self._hp)), ('classification.bias', (self.n_out,))])
         init['classification.weight'], init['classification.bias'] = cw, cb
-        self._init_flat(FlatLayout(groups), init)
+        if _head_pad(hidden_dim, 2):
+            pads['classification.weight'] = _head_pad(hidden_dim, 2)
+        self._init_flat(FlatLayout(groups, pads), init)
         self._rnn = _RnnStack(self, 'model.', embedding_dim, hidden_dim, num_layers, 'r')
 
     def _fwd(self, xs, lengths):
@@ -178,7 +202,7 @@ class BiLSTM(_RnnTaggerBase):
         if want_grad:
             g, lay = self.grad_flat(), self._layout
             ops.head_bwd_params(st['h'], dsc, lay.view(g, 'classification.weight'), lay.view(g, 'classification.bias'))
-            dout = self._ws.get('dout', B * Lq, 2 * self.hidden_dim, self.compute_dtype, dev)
+            dout = self._ws.get('dout', B * Lq, 2 * self._hp, self.compute_dtype, dev)
             ops.head_bwd_data(dsc, self._w(self._flat, 'classification.weight'), dout)
             self._rnn.backward(st['saved'], dout, st['li32'], B, Lq)
         return loss_out[0], st['scores']
@@ -213,19 +237,23 @@ class BiLSTMLateFusion(_RnnTaggerBase):
         self.embedding_dim, self.hidden_dim, self.tagset_size, self.num_layers = embedding_dim, hidden_dim, tagset_size, num_layers
         self.n_out = tagset_size if loss_fn == 'CrossEntropy' else 1
         gen = torch.Generator().manual_seed(torch.initial_seed() if seed is None else seed)
-        g1, i1 = _rnn_groups('model1.', embedding_dim[0], hidden_dim, num_layers, gen)
-        g2, i2 = _rnn_groups('model2.', embedding_dim[1], hidden_dim, num_layers, gen)
+        g1, i1, p1 = _rnn_groups('model1.', embedding_dim[0], hidden_dim, num_layers, gen)
+        g2, i2, p2 = _rnn_groups('model2.', embedding_dim[1], hidden_dim, num_layers, gen)
+        self._hp = round_up(hidden_dim, 8)
         cw, cb = _linear_init(self.n_out, 4 * hidden_dim, gen)
-        groups = g1 + g2 + [[('classification.weight', (self.n_out, 4 * hidden_dim)), ('classification.bias', (self.n_out,))]]
+        groups = g1 + g2 + [[('classification.weight', (self.n_out, 4 * self._hp)), ('classification.bias', (self.n_out,))]]
         init = {**i1, **i2, 'classification.weight': cw, 'classification.bias': cb}
-        self._init_flat(FlatLayout(groups), init)
+        pads = {**p1, **p2}
+        if _head_pad(hidden_dim, 4):
+            pads['classification.weight'] = _head_pad(hidden_dim, 4)
+        self._init_flat(FlatLayout(groups, pads), init)
         self._rnn1 = _RnnStack(self, 'model1.', embedding_dim[0], hidden_dim, num_layers, 'r1')
         self._rnn2 = _RnnStack(self, 'model2.', embedding_dim[1], hidden_dim, num_layers, 'r2')
 
     def _fwd(self, x1, x2, lengths):
         xa, Lq = self._prep_input(x1, lengths)
         xb, _ = self._prep_input(x2, lengths)
-        B, H = xa.shape[0], self.hidden_dim
+        B, H = xa.shape[0], self._hp
         li32 = self._prep_lengths(lengths, B, Lq, x1.device)
         h1, s1 = self._rnn1.forward(self._to_act(xa), li32, B, Lq)
         h2, s2 = self._rnn2.forward(self._to_act(xb), li32, B, Lq)
@@ -239,7 +267,7 @@ class BiLSTMLateFusion(_RnnTaggerBase):
     def loss_and_grad(self, x1, x2, lengths, tags, want_grad=True):
         L.require_gpu()
         st = self._fwd(x1, x2, lengths)
-        dev, B, Lq, H = x1.device, st['B'], st['L'], self.hidden_dim
+        dev, B, Lq, H = x1.device, st['B'], st['L'], self._hp
         tg = tags.to(device=dev, dtype=torch.float32).contiguous()
         loss_out = torch.empty(2, dtype=torch.float32, device=dev)
         dsc = self._ws.get('dscores', B * Lq, self.n_out, torch.float32, dev) if want_grad else None
@@ -289,16 +317,19 @@ class BiRnnCrf(_RnnTaggerBase):
         if self.num_tags > 4:
             raise NotImplementedError('CRF head supports tagset_size <= 2 (fused head kernels cover <= 4 outputs)')
         gen = torch.Generator().manual_seed(torch.initial_seed() if seed is None else seed)
-        groups, init = _rnn_groups('model.', embedding_dim, hidden_dim, num_layers, gen)
+        groups, init, pads = _rnn_groups('model.', embedding_dim, hidden_dim, num_layers, gen)
+        self._hp = round_up(hidden_dim, 8)
         C = self.num_tags
         fw, fb = _linear_init(C, 2 * hidden_dim, gen)
         trans = torch.randn(C, C, generator=gen)
         trans[self.start_idx, :] = IMPOSSIBLE                 # models/CRF.py:115-117
         trans[:, self.stop_idx] = IMPOSSIBLE
-        groups.append([('crf.fc.weight', (C, 2 * hidden_dim)), ('crf.fc.bias', (C,))])
+        groups.append([('crf.fc.weight', (C, 2 * self._hp)), ('crf.fc.bias', (C,))])
         groups.append([('crf.transitions', (C, C))])
         init.update({'crf.fc.weight': fw, 'crf.fc.bias': fb, 'crf.transitions': trans})
-        self._init_flat(FlatLayout(groups), init)
+        if _head_pad(hidden_dim, 2):
+            pads['crf.fc.weight'] = _head_pad(hidden_dim, 2)
+        self._init_flat(FlatLayout(groups, pads), init)
         self._rnn = _RnnStack(self, 'model.', embedding_dim, hidden_dim, num_layers, 'r')
 
     def _fwd(self, xs, lengths):
@@ -322,7 +353,7 @@ class BiRnnCrf(_RnnTaggerBase):
                     dfe.view(B, Lq, C) if want_grad else None, lay.view(g, 'crf.transitions') if want_grad else None)
         if want_grad:
             ops.head_bwd_params(st['h'], dfe, lay.view(g, 'crf.fc.weight'), lay.view(g, 'crf.fc.bias'))
-            dout = self._ws.get('dout', B * Lq, 2 * self.hidden_dim, self.compute_dtype, dev)
+            dout = self._ws.get('dout', B * Lq, 2 * self._hp, self.compute_dtype, dev)
             ops.head_bwd_data(dfe, self._w(self._flat, 'crf.fc.weight'), dout)
             self._rnn.backward(st['saved'], dout, st['li32'], B, Lq)
         return loss_out[0], st['feats']

@@ -25,7 +25,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import ops
-from .flat import FlatLayout, FlatModule
+from .flat import FlatLayout, FlatModule, round_up
 
 LOSS_KINDS = {'CrossEntropy': L.LOSS_CE, 'BinaryCrossEntropy': L.LOSS_BCE, 'FocalLoss': L.LOSS_FOCAL}
 DEAD_HF_KEYS = ('word_embeddings', 'query_global', 'key_global', 'value_global', 'pooler', 'position_ids', 'token_type_ids')
@@ -196,11 +196,14 @@ class Transformer_segmenter(_TaggerBase):
 
         gen = torch.Generator().manual_seed(torch.initial_seed() if seed is None else seed)
         std = 0.02                                         # HF initializer_range
-        groups, init = [], {}
+        groups, init, pads = [], {}, {}
+        Fp = self._ffp = round_up(F, 8)                    # FFN width as stored (the reference's default is 25): flat.py "padded storage"
 
-        def add(group, name, shape, value):
-            group.append((name, shape))
+        def add(group, name, shape, value, pad=None, storage=None):
+            group.append((name, storage or shape))
             init[name] = value
+            if pad and storage != shape:
+                pads[name] = pad
 
         e = 'model.model.embeddings.'
         g = []
@@ -235,14 +238,21 @@ class Transformer_segmenter(_TaggerBase):
                     ('output.LayerNorm.weight', (D,), torch.ones(D)),
                     ('output.LayerNorm.bias', (D,), torch.zeros(D))):
                 g = []
-                add(g, lp + name, shape, val)
+                if name == 'intermediate.dense.weight':
+                    add(g, lp + name, shape, val, pad=[(0, 1, F, Fp)], storage=(Fp, D))
+                elif name == 'intermediate.dense.bias':
+                    add(g, lp + name, shape, val, pad=[(0, 1, F, Fp)], storage=(Fp,))
+                elif name == 'output.dense.weight':
+                    add(g, lp + name, shape, val, pad=[(1, 1, F, Fp)], storage=(D, Fp))
+                else:
+                    add(g, lp + name, shape, val)
                 groups.append(g)
         cw, cb = _linear_init(self.n_out, D, gen)
         g = []
         add(g, 'classification.weight', (self.n_out, D), cw)
         add(g, 'classification.bias', (self.n_out,), cb)
         groups.append(g)
-        self._init_flat(FlatLayout(groups), init)
+        self._init_flat(FlatLayout(groups, pads), init)
         self._register_load_state_dict_pre_hook(self._drop_dead_keys)
 
     @staticmethod
@@ -261,7 +271,7 @@ class Transformer_segmenter(_TaggerBase):
             raise ValueError(f'expected input dim {self.embedding_dim}, got {D}')
         if Lq + 2 > self.max_pos:
             raise ValueError(f'sequence length {Lq} exceeds max_position_embeddings-2 = {self.max_pos - 2}')
-        N, F, H = (pack['n'] if pack else B * Lq), self.hidden_dim, self.nheads
+        N, F, H = (pack['n'] if pack else B * Lq), self._ffp, self.nheads
         row_src, row0 = (pack['row_src'], pack['row0']) if pack else (None, None)
         ws, lay = self._ws, self._layout
         wf = self._weights()                  # compute-dtype mirror (GEMM operands)
@@ -323,7 +333,7 @@ class Transformer_segmenter(_TaggerBase):
         """Fill grad_flat from the saved forward state; dscores fp32 [N, n_out]."""
         dt = self.compute_dtype
         B, Lq, N = st['B'], st['L'], st['N']
-        D, F, H = self.embedding_dim, self.hidden_dim, self.nheads
+        D, F, H = self.embedding_dim, self._ffp, self.nheads
         dev = dscores.device
         ws, lay = self._ws, self._layout
         wf, pf = self._weights(), self._flat

@@ -27,7 +27,7 @@ def _check_grads(model, ref_grads, rtol, atol, skip=()):
     for n, p in model.named_parameters():
         if n not in ref_grads or any(s in n for s in skip):
             continue
-        got = p.grad.detach().float().cpu().numpy()
+        got = model.logical_view({n: p.grad}, n).detach().float().cpu().numpy()   # sizes that are not multiples of 8 are stored padded
         ref = ref_grads[n]
         if got.shape != ref.shape:
             got = got[: ref.shape[0]]
@@ -439,3 +439,170 @@ def test_packed_batch_gives_the_same_loss_and_gradients(dtype, D, heads, window,
     assert err < (2e-5 if f32 else 2e-2) * scale, (err, scale)
     m.pack_rows = 'auto'
     assert m._pack_plan(lengths, B, L, x.device) is not None and m._pack_plan(torch.full((B,), L), B, L, x.device) is None
+
+
+# ------------------------------------------------------------------------------------------------ randomized shapes (fp32 parity mode)
+def _rand_case(seed):
+    rng = np.random.default_rng(seed)
+    heads = int(rng.choice([1, 2, 4]))
+    hd = int(rng.choice([8, 12, 16, 32]))
+    D = heads * hd
+    B = int(rng.integers(1, 6))
+    L = int(rng.integers(1, 70))
+    NL = int(rng.integers(1, 4))
+    window = int(2 * rng.integers(1, 9))                        # one-sided radius 1..8 for the last layer
+    lengths = rng.integers(1, L + 1, B)
+    lengths[rng.integers(0, B)] = L                             # the collater pads to the longest document
+    loss_fn = str(rng.choice(['FocalLoss', 'BinaryCrossEntropy', 'CrossEntropy']))
+    return B, L, D, heads, NL, window, lengths.astype(np.int64), loss_fn, int(rng.integers(8, 40))
+
+
+@pytest.mark.parametrize('seed', list(range(12)))
+def test_transformer_random_shapes_fp32(seed):
+    """Scores, loss, gradients and boundary lists against the oracle on random small configurations (1-3 pyramidal layers,
+    1-4 heads, head dims 8..32, ragged lengths down to 1, documents shorter than the window), padded AND packed paths."""
+    from oracle import restatement as R
+    from multimodaltopicsegmentation_amd.taggers import Transformer_segmenter
+    B, L, D, heads, NL, window, lengths, loss_fn, ff = _rand_case(1000 + seed)
+    m = Transformer_segmenter(2, D, ff, num_layers=NL, nheads=heads, loss_fn=loss_fn, window_size=window, compute_dtype='fp32',
+                              max_position_embedding=128, seed=seed).to(DEV)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, L, D, generator=g)
+    pad = 0.0 if loss_fn != 'CrossEntropy' else -1.0
+    y = torch.full((B, L), -1.0)
+    for b, n in enumerate(lengths.tolist()):
+        x[b, n:] = 0.0
+        y[b, :n] = (torch.rand(n, generator=g) < 0.3).float()
+    lens = torch.from_numpy(lengths)
+    p = {k: v.detach().cpu().double().requires_grad_(True) for k, v in m.state_dict().items()}
+    ref = R.transformer_scores(x.double(), lens, p, heads, R.pyramidal_radii(NL, window))
+    ref_loss = R.tagger_loss(ref, lens, y.double(), loss_fn)
+    ref_loss.backward()
+    m.th = 0.5
+    scores, tags = m(x.to(DEV), lens)
+    np.testing.assert_allclose(scores.cpu().numpy(), ref.detach().numpy(), atol=3e-5, rtol=0)      # every row, padded ones too
+    ref_tags = R.greedy_decode(ref.detach().float(), lens, 0.5, loss_fn != 'CrossEntropy')
+    prob = torch.sigmoid(ref.detach()[..., 0]) if loss_fn != 'CrossEntropy' else torch.softmax(ref.detach(), -1)[..., 1]
+    for b, n in enumerate(lengths.tolist()):
+        for i in range(n):
+            if abs(float(prob[b, i]) - 0.5) > 1e-4:
+                assert tags[b][i] == ref_tags[b][i], (b, i)
+    for packed in (False, True):
+        m.pack_rows = packed
+        loss, _ = m.loss_and_grad(x.to(DEV), lens, y.to(DEV), True)
+        assert abs(loss.item() - ref_loss.item()) < 3e-6 * max(1.0, abs(ref_loss.item())), (packed, loss.item(), ref_loss.item())
+        views = m.grad_views()
+        for n_ in views:
+            r = p[n_].grad
+            if r is None:
+                continue
+            a = m.logical_view(views, n_).detach().cpu().double()      # FFN widths that are not multiples of 8 are stored padded
+            if 'position_embeddings' in n_:
+                assert float(a[L + 2:].abs().max()) == 0.0 if a.shape[0] > L + 2 else True
+            scale = max(float(r.abs().max()), 1e-8)
+            assert float((a - r).abs().max()) < 3e-3 * scale + 2e-7, (packed, n_)
+
+
+# ------------------------------------------------------------------------------------------------ the reference's default hidden size (25)
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('arch', ['BiLSTM', 'BiLSTMLateFusion', 'biLSTMCRF'])
+def test_default_hidden_size_25_recurrent(arch, dtype):
+    """hidden_units defaults to 25 (train_fit.py:689) and inputs may carry 2 timing features (768 + 2): sizes that are not
+    multiples of 8 are stored padded with inert units; state_dict keeps the reference's shapes; results match the oracle."""
+    from oracle import restatement as R
+    from multimodaltopicsegmentation_amd import TextSegmenter
+    B, L, Hd, NL = 4, 23, 25, 2
+    lengths = torch.tensor([23, 9, 1, 16])
+    g = torch.Generator().manual_seed(41)
+    dims = [50, 26] if arch == 'BiLSTMLateFusion' else 50            # 26, 50: not multiples of 8 (48 + 2 timing features)
+    ts = TextSegmenter(2, dims, Hd, num_layers=NL, architecture=arch, loss_fn='FocalLoss', compute_dtype=dtype).to(DEV)
+    m = ts.model
+    sd = m.state_dict()
+    assert sd[[k for k in sd if k.endswith('rnn.weight_hh_l0')][0]].shape == (100, 25)          # reference shapes, not the padded storage
+    assert sd[[k for k in sd if k.endswith('rnn.weight_ih_l1')][0]].shape == (100, 50)
+    p = {k: v.detach().cpu().double().requires_grad_(True) for k, v in sd.items()}
+    f32 = dtype == 'fp32'
+    if arch == 'BiLSTMLateFusion':
+        x1, x2 = torch.randn(B, L, 50, generator=g), torch.randn(B, L, 26, generator=g)
+    else:
+        x1, x2 = torch.randn(B, L, 50, generator=g), None
+    y = torch.full((B, L), -1.0 if arch != 'biLSTMCRF' else 0.0)
+    for b, n in enumerate(lengths.tolist()):
+        y[b, :n] = (torch.rand(n, generator=g) < 0.3).float()
+    if arch == 'BiLSTM':
+        ref = R.bilstm_scores(x1.double(), lengths, p, NL)
+        ref_loss = R.tagger_loss(ref, lengths, y.double()[:, :int(lengths.max())], 'FocalLoss')
+        loss = m.loss(x1.to(DEV), lengths, y.to(DEV))
+    elif arch == 'BiLSTMLateFusion':
+        ref = R.late_fusion_scores(x1.double(), x2.double(), lengths, p, NL)
+        ref_loss = R.tagger_loss(ref, lengths, y.double()[:, :int(lengths.max())], 'FocalLoss')
+        loss = m.loss(x1.to(DEV), x2.to(DEV), lengths, y.to(DEV))
+    else:
+        h = R.rnn_forward(x1.double(), lengths, p, 'model.', NL, True)
+        mask = R.create_mask(h.shape[1], lengths)
+        ref_loss = R.crf_nll(h, y.long()[:, :h.shape[1]], mask, p['crf.fc.weight'], p['crf.fc.bias'], p['crf.transitions'])
+        loss = m.loss(x1.to(DEV), lengths, y.long().to(DEV))
+    ref_loss.backward()
+    loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < (5e-6 if f32 else 3e-2) * max(1.0, abs(ref_loss.item()))
+    grads = {n: prm.grad for n, prm in m.named_parameters()}
+    for n in grads:
+        r = p[n].grad
+        if r is None:
+            continue
+        a = m.logical_view(grads, n).detach().cpu().double()
+        assert a.shape == r.shape, n
+        scale = max(float(r.abs().max()), 1e-8)
+        assert float((a - r).abs().max()) < (3e-3 if f32 else 0.15) * scale + (2e-7 if f32 else 3e-4), n
+        full = grads[n].detach().cpu()
+        assert abs(float(full.double().abs().sum()) - float(a.abs().sum())) <= 1e-6 * max(1.0, float(a.abs().sum()))   # padded units get no gradient
+    # checkpoint round trip in the reference's shapes
+    ts2 = TextSegmenter(2, dims, Hd, num_layers=NL, architecture=arch, loss_fn='FocalLoss', compute_dtype=dtype).to(DEV)
+    ts2.model.load_state_dict(sd)
+    if arch == 'BiLSTMLateFusion':
+        a_, b_ = m(x1.to(DEV), x2.to(DEV), lengths)[0], ts2.model(x1.to(DEV), x2.to(DEV), lengths)[0]
+    else:
+        a_, b_ = m(x1.to(DEV), lengths)[0], ts2.model(x1.to(DEV), lengths)[0]
+    assert torch.equal(a_, b_)
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_default_hidden_size_25_transformer(dtype):
+    from oracle import restatement as R
+    from multimodaltopicsegmentation_amd import TextSegmenter
+    B, L, D, heads, window = 3, 37, 64, 4, 8
+    lengths = torch.tensor([37, 20, 3])
+    ts = TextSegmenter(2, D, 25, num_layers=2, architecture='Transformer', loss_fn='FocalLoss', nheads=heads, attention_window=window,
+                       compute_dtype=dtype).to(DEV)
+    m = ts.model
+    sd = m.state_dict()
+    assert sd['model.model.encoder.layer.0.intermediate.dense.weight'].shape == (25, D)
+    assert sd['model.model.encoder.layer.1.output.dense.weight'].shape == (D, 25)
+    p = {k: v.detach().cpu().double().requires_grad_(True) for k, v in sd.items()}
+    g = torch.Generator().manual_seed(43)
+    x = torch.randn(B, L, D, generator=g)
+    y = torch.full((B, L), -1.0)
+    for b, n in enumerate(lengths.tolist()):
+        x[b, n:] = 0.0
+        y[b, :n] = (torch.rand(n, generator=g) < 0.3).float()
+    ref = R.transformer_scores(x.double(), lengths, p, heads, R.pyramidal_radii(2, window))
+    ref_loss = R.tagger_loss(ref, lengths, y.double(), 'FocalLoss')
+    ref_loss.backward()
+    f32 = dtype == 'fp32'
+    loss = m.loss(x.to(DEV), lengths, y.to(DEV))
+    loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < (3e-6 if f32 else 2e-2) * max(1.0, abs(ref_loss.item()))
+    scores, _ = m(x.to(DEV), lengths)
+    np.testing.assert_allclose(scores.cpu().numpy(), ref.detach().numpy(), atol=3e-5 if f32 else 6e-2, rtol=0)
+    grads = {n: prm.grad for n, prm in m.named_parameters()}
+    for n in grads:
+        r = p[n].grad
+        if r is None or 'key.bias' in n:
+            continue
+        a = m.logical_view(grads, n).detach().cpu().double()
+        scale = max(float(r.abs().max()), 1e-8)
+        assert float((a - r).abs().max()) < (3e-3 if f32 else 0.12) * scale + (2e-7 if f32 else 3e-4), n
+    ts2 = TextSegmenter(2, D, 25, num_layers=2, architecture='Transformer', loss_fn='FocalLoss', nheads=heads, attention_window=window,
+                        compute_dtype=dtype).to(DEV)
+    ts2.model.load_state_dict(sd)
+    assert torch.equal(ts2.model(x.to(DEV), lengths)[0], scores)
