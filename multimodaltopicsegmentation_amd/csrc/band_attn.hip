@@ -343,7 +343,7 @@ static int band_fill(BandArgs& a, int dtype, int B, int L, int D, int heads, int
   MTS_CHECK_ARG(dtype == MTS_F32 || dtype == MTS_BF16, "%s: bad dtype %d", who, dtype);
   const int hd = D / heads;
   const int vec = dtype == MTS_F32 ? 4 : 8;
-  MTS_UNSUPPORTED(hd % vec == 0 && hd <= 256, "%s: head dim %d must be a multiple of %d and <= 256", who, hd, vec);
+  MTS_UNSUPPORTED(hd % vec == 0 && hd <= 512, "%s: head dim %d must be a multiple of %d and <= 512", who, hd, vec);
   MTS_UNSUPPORTED((long)B * L * heads * (long)band_slots(radius) < (1L << 31), "%s: problem too large for 32-bit slot indexing", who);
   a.B = B; a.L = L; a.D = D; a.heads = heads; a.hd = hd; a.radius = radius; a.slots = band_slots(radius);
   a.rs = band_row_stride(hd, dtype == MTS_F32 ? 4 : 2);
@@ -367,7 +367,7 @@ template <typename T>
 static int band_fwd_launch(const BandArgs& a, hipStream_t st) {
   const size_t lds = (size_t)(TQ + KV_ROWS) * a.rs + (size_t)TQ * a.ps * sizeof(float);
   const int nblocks = ceil_div(a.L, TQ) * a.heads * a.B;
-  auto k = band_fwd_kernel<T, 8>;
+  auto k = a.hd > 256 ? band_fwd_kernel<T, 16> : band_fwd_kernel<T, 8>;       // 8 lanes x MAXU chunks of 4 cover the head dim
   int rc = set_lds(k, lds, "mts_band_attn_fwd");
   if (rc) return rc;
   hipLaunchKernelGGL(k, dim3(nblocks), dim3(256), lds, st, a);
@@ -396,14 +396,14 @@ static int band_bwd_launch(const BandArgs& a, hipStream_t st) {
   const int nblocks = ceil_div(a.L, TQ) * a.heads * a.B;
   {
     const size_t lds = (size_t)(TQ + KV_ROWS) * a.rs + (size_t)TQ * a.ps * sizeof(float);
-    auto k = band_bwd_q_kernel<T, 8>;
+    auto k = a.hd > 256 ? band_bwd_q_kernel<T, 16> : band_bwd_q_kernel<T, 8>;
     int rc = set_lds(k, lds, "mts_band_attn_bwd(q)");
     if (rc) return rc;
     hipLaunchKernelGGL(k, dim3(nblocks), dim3(256), lds, st, a);
   }
   {
     const size_t lds = (size_t)KV_ROWS * a.rs + (size_t)(KV_ROWS * 32 + TQ * 33) * sizeof(float);
-    auto k = band_bwd_kv_kernel<T, 8>;
+    auto k = a.hd > 256 ? band_bwd_kv_kernel<T, 16> : band_bwd_kv_kernel<T, 8>;
     int rc = set_lds(k, lds, "mts_band_attn_bwd(kv)");
     if (rc) return rc;
     hipLaunchKernelGGL(k, dim3(nblocks), dim3(256), lds, st, a);

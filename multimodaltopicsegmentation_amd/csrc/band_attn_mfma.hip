@@ -450,7 +450,10 @@ static int pick_nkb(const BandArgs& a) {
   switch (a.hd / 32) {                                                                                \
     case 1: return launch(KERNEL<1, NKBV, OCC>, __VA_ARGS__);                                         \
     case 2: return launch(KERNEL<2, NKBV, OCC>, __VA_ARGS__);                                         \
+    case 3: return launch(KERNEL<3, NKBV, OCC>, __VA_ARGS__);                                         \
     case 4: return launch(KERNEL<4, NKBV, OCC>, __VA_ARGS__);                                         \
+    case 5: return launch(KERNEL<5, NKBV, OCC>, __VA_ARGS__);                                         \
+    case 6: return launch(KERNEL<6, NKBV, OCC>, __VA_ARGS__);                                         \
     case 7: return launch(KERNEL<7, NKBV, OCC>, __VA_ARGS__);                                         \
     case 8: return launch(KERNEL<8, NKBV, OCC>, __VA_ARGS__);                                         \
     default: return -1;                                                                               \
@@ -477,7 +480,7 @@ static int dispatch(const BandArgs& a, hipStream_t st, const char* who) {
 
 static bool covered(const BandArgs& a) {
   const int k = a.hd / 32;
-  return pick_nkb(a) != 0 && (k == 1 || k == 2 || k == 4 || k == 7 || k == 8);
+  return pick_nkb(a) != 0 && k >= 1 && k <= 8;        // head dims 32, 64, .., 256 (768/8 = 96, 1024/8 = 128, 1536/8 = 192, 1792/8 = 224)
 }
 
 int mts_band_mfma_fwd(const BandArgs& a, hipStream_t st) {

@@ -185,7 +185,9 @@ __global__ __launch_bounds__(256) void head_bwd_data_kernel(const float* __restr
 //   slab layout (fp32): partial[block][slot][D], slots: 0 dgamma, 1 dbeta, 2 colsum(dx)
 //   MODE 0: LayerNorm backward.  MODE 1: head parameter gradient (slots 0..n_out-1 = dw rows; db via slot 4.. see below)
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NV>
+// WIDE (D > 2048): blockIdx.y picks a chunk of NV*256 columns whose dx / column sums this workgroup produces; the row
+// statistics s1, s2 need the whole row, so the other chunks are read once more for them.
+template <typename T, int NV, bool WIDE>
 __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
     const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ dlogit, const float* __restrict__ head_w, int n_out,
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd, int rows, int D,
@@ -193,6 +195,7 @@ __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
   __shared__ float red[ROW_WAVES][3][64 * 4];   // one vector slot at a time is combined through LDS
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  const int col0 = WIDE ? (int)blockIdx.y * (NV * 256) : 0;
   float dg[NV][4], db[NV][4], dxs[NV][4];
 #pragma unroll
   for (int i = 0; i < NV; ++i)
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
   auto fetch = [&](int r) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int e = 4 * (lane + 64 * i);
+      const int e = col0 + 4 * (lane + 64 * i);
       if (e < D) {
         px[i].load(x + (size_t)r * D + e);
         if (dy) pd[i].load(dy + (size_t)r * D + e);
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
     if (head_w) for (int c = 0; c < n_out; ++c) dl[c] = dlogit[(size_t)row * n_out + c];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int e = 4 * (lane + 64 * i);
+      const int e = col0 + 4 * (lane + 64 * i);
       if (e < D) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { xh[i][j] = px[i].get(j); gy[i][j] = dy ? pd[i].get(j) : 0.f; }
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
     if (row + stride < rows) fetch(row + stride);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int e = 4 * (lane + 64 * i);
+      const int e = col0 + 4 * (lane + 64 * i);
       if (e < D) {
         float dv[4], gv[4];
         load4<float>(gamma + e, gv);          // L1/L2-resident; keeping gamma in registers would cost NV*4 VGPRs
@@ -261,11 +264,36 @@ __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
         for (int j = 0; j < 4; ++j) { xh[i][j] = 0.f; gy[i][j] = 0.f; }
       }
     }
+    if constexpr (WIDE) {
+      for (int oc = 0; oc < (int)gridDim.y; ++oc) {
+        if (oc == (int)blockIdx.y) continue;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const int e = oc * (NV * 256) + 4 * (lane + 64 * i);
+          if (e < D) {
+            float xv[4], dv[4] = {0.f, 0.f, 0.f, 0.f}, gv[4];
+            load4<T>(x + (size_t)row * D + e, xv);
+            if (dy) load4<T>(dy + (size_t)row * D + e, dv);
+            load4<float>(gamma + e, gv);
+            if (head_w) {
+              for (int c = 0; c < n_out; ++c) {
+                float wv[4];
+                load4<float>(head_w + (size_t)c * D + e, wv);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dv[j] += dl[c] * wv[j];
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float gyv = dv[j] * gv[j]; s1 += gyv; s2 += gyv * ((xv[j] - mu) * rs); }
+          }
+        }
+      }
+    }
     s1 = wave_sum(s1) * invD;
     s2 = wave_sum(s2) * invD;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int e = 4 * (lane + 64 * i);
+      const int e = col0 + 4 * (lane + 64 * i);
       if (e < D) {
         float o[4];
 #pragma unroll
@@ -292,7 +320,7 @@ __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
     __syncthreads();
     for (int t = threadIdx.x; t < 3 * 256; t += 64 * ROW_WAVES) {
       const int slot = t / 256, col = t % 256;
-      const int e = 256 * i + col;
+      const int e = col0 + 256 * i + col;
       if (e < D) {
         float s = 0.f;
 #pragma unroll
@@ -310,6 +338,7 @@ __global__ __launch_bounds__(64 * ROW_WAVES) void head_bwd_params_kernel(const T
   __shared__ float red[ROW_WAVES][4][64 * 4];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  const int col0 = (int)blockIdx.y * (NV * 256);                  // D > NV*256: blockIdx.y picks the column chunk
   float dw[4][NV][4];
 #pragma unroll
   for (int c = 0; c < 4; ++c)
@@ -325,7 +354,7 @@ __global__ __launch_bounds__(64 * ROW_WAVES) void head_bwd_params_kernel(const T
     for (int c = 0; c < 4; ++c) dbs[c] += dl[c];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int e = 4 * (lane + 64 * i);
+      const int e = col0 + 4 * (lane + 64 * i);
       if (e < D) {
         float xv[4];
         load4<T>(x + (size_t)row * ldx + e, xv);
@@ -348,7 +377,7 @@ __global__ __launch_bounds__(64 * ROW_WAVES) void head_bwd_params_kernel(const T
     __syncthreads();
     for (int t = threadIdx.x; t < 4 * 256; t += 64 * ROW_WAVES) {
       const int slot = t / 256, col = t % 256;
-      const int e = 256 * i + col;
+      const int e = col0 + 256 * i + col;
       if (e < D) {
         float s = 0.f;
 #pragma unroll
@@ -547,13 +576,18 @@ static int ln_bwd_launch(hipStream_t st, int rows, int D, const void* x, const v
                          const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, float* dxsum,
                          void* partial) {
   const int nv = pick_nv(D);
-  MTS_UNSUPPORTED(nv > 0 && nv <= 8 && D % 4 == 0, "layernorm_bwd: D=%d must be a multiple of 4 and <= 2048", D);
+  MTS_UNSUPPORTED(nv > 0 && D % 4 == 0, "layernorm_bwd: D=%d must be a multiple of 4 and <= 4096", D);
   const int blocks = std::min(BWD_MAX_BLOCKS, ceil_div(rows, ROW_WAVES));
-  dispatch_nv8(nv, [&](auto nvc) {
-    constexpr int NV = decltype(nvc)::value;
-    hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), dim3(blocks), dim3(64 * ROW_WAVES), 0, st, (const T*)x, (const T*)dy, dlogit, head_w, n_out, gamma,
-                       mean, rstd, rows, D, (T*)dx, (float*)partial);
-  });
+  if (nv <= 8) {
+    dispatch_nv8(nv, [&](auto nvc) {
+      constexpr int NV = decltype(nvc)::value;
+      hipLaunchKernelGGL((ln_bwd_kernel<T, NV, false>), dim3(blocks), dim3(64 * ROW_WAVES), 0, st, (const T*)x, (const T*)dy, dlogit, head_w, n_out,
+                         gamma, mean, rstd, rows, D, (T*)dx, (float*)partial);
+    });
+  } else {   // 2048 < D <= 4096 (e.g. 768 + 1536 = 2304): two column chunks of 2048
+    hipLaunchKernelGGL((ln_bwd_kernel<T, 8, true>), dim3(blocks, ceil_div(D, 2048)), dim3(64 * ROW_WAVES), 0, st, (const T*)x, (const T*)dy, dlogit,
+                       head_w, n_out, gamma, mean, rstd, rows, D, (T*)dx, (float*)partial);
+  }
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(D, SR_COLS), 3), dim3(256), 0, st, (const float*)partial, blocks, 3, D, dgamma, dbeta,
                      dxsum, (float*)nullptr, (float*)nullptr, 0);
   MTS_LAUNCH_CHECK("layernorm_bwd");
@@ -604,19 +638,20 @@ extern "C" int mts_head_bwd_params(void* stream, int dtype, int rows, int D, int
   MTS_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && n_out >= 1 && n_out <= 4 && x && dscores && dw && db && partial,
                 "mts_head_bwd_params: bad arguments");
   const int nv = pick_nv(D);
-  MTS_UNSUPPORTED(nv > 0 && nv <= 8, "mts_head_bwd_params: D=%d must be <= 2048", D);
+  MTS_UNSUPPORTED(nv > 0, "mts_head_bwd_params: D=%d must be <= 4096", D);
   hipStream_t st = (hipStream_t)stream;
   const int blocks = std::min(BWD_MAX_BLOCKS, ceil_div(rows, ROW_WAVES));
+  const int chunks = nv <= 8 ? 1 : ceil_div(D, 2048);             // 2048 < D <= 4096: two column chunks
   if (dtype == MTS_F32) {
     dispatch_nv8(nv, [&](auto nvc) {
       constexpr int NV = decltype(nvc)::value;
-      hipLaunchKernelGGL((head_bwd_params_kernel<float, NV>), dim3(blocks), dim3(64 * ROW_WAVES), 0, st, (const float*)x, ldx, dscores, n_out,
+      hipLaunchKernelGGL((head_bwd_params_kernel<float, NV>), dim3(blocks, chunks), dim3(64 * ROW_WAVES), 0, st, (const float*)x, ldx, dscores, n_out,
                          rows, D, (float*)partial);
     });
   } else if (dtype == MTS_BF16) {
     dispatch_nv8(nv, [&](auto nvc) {
       constexpr int NV = decltype(nvc)::value;
-      hipLaunchKernelGGL((head_bwd_params_kernel<bf16_t, NV>), dim3(blocks), dim3(64 * ROW_WAVES), 0, st, (const bf16_t*)x, ldx, dscores, n_out,
+      hipLaunchKernelGGL((head_bwd_params_kernel<bf16_t, NV>), dim3(blocks, chunks), dim3(64 * ROW_WAVES), 0, st, (const bf16_t*)x, ldx, dscores, n_out,
                          rows, D, (float*)partial);
     });
   } else { mts_set_error("mts_head_bwd_params: bad dtype %d", dtype); return MTS_ERR_INVALID; }

@@ -178,7 +178,7 @@ def test_colsum_cast(ops, dtype):
 
 # ------------------------------------------------------------------------------------------------ LayerNorm family
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('D', [64, 96, 1792])
+@pytest.mark.parametrize('D', [64, 96, 1792, 2304])
 def test_layernorm_fwd_bwd(ops, dtype, D):
     rows, eps = 301, 1e-12
     x = (_rnd(rows, D, seed=11) * 1.7 + 0.3).to(dtype)
@@ -274,6 +274,9 @@ def test_gelu_bwd_and_head(ops, dtype):
     (1, 200, 128, 2, 63, [170]),             # hd 64, the reference's default window 127 -> 10 key blocks
     (2, 256, 512, 2, 40, None),              # hd 256, 96 slots
     (3, 128, 256, 2, 15, [128, 1, 127]),     # hd 128, exactly one tile
+    (2, 140, 192, 2, 15, [140, 60]),         # hd 96  = 768 / 8 heads (RoBERTa / wav2vec widths)
+    (1, 130, 384, 2, 60, [130]),             # hd 192 = 1536 / 8 heads, the default attention_window 120
+    (2, 70, 576, 2, 15, [70, 9]),            # hd 288 = 2304 / 8 heads (768 + 1536): above the matrix-core kernels' 256 -> generic kernels
 ])
 def test_band_attention_fwd_bwd(ops, dtype, B, Lq, D, heads, radius, lengths):
     hd = D // heads
