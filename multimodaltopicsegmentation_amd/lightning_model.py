@@ -185,7 +185,11 @@ class TextSegmenter(_Base):
 
     # ---- lightning_model.py:678-683 -------------------------------------------------------------------
     def predict_step(self, batch, batch_idx):
-        score, tags = self.model(batch['src_tokens'], batch['src_lengths'])
+        if getattr(self, 'double_input', False) and batch.get('src_tokens2') is not None:
+            # the reference calls model(sentence, lengths) here and raises TypeError for late-fusion models; serve them instead
+            score, tags = self.model(batch['src_tokens'], batch['src_tokens2'], batch['src_lengths'])
+        else:
+            score, tags = self.model(batch['src_tokens'], batch['src_lengths'])
         return tags
 
     # ---- lightning_model.py:759-781 -------------------------------------------------------------------
