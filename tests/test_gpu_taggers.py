@@ -606,3 +606,37 @@ def test_default_hidden_size_25_transformer(dtype):
                         compute_dtype=dtype).to(DEV)
     ts2.model.load_state_dict(sd)
     assert torch.equal(ts2.model(x.to(DEV), lengths)[0], scores)
+
+
+# ------------------------------------------------------------------------------------------------ boundary: option matrix
+@pytest.mark.parametrize('arch', ['biLSTMCRF', 'BiLSTM', 'BiLSTMLateFusion', 'Transformer'])
+def test_text_segmenter_option_matrix(arch):
+    """Every step function of the drop-in class over losses x optimizers x metrics x end_boundary x threshold with the
+    reference's default hidden size (25), from collated ragged documents (tools/probe_segmenter.py runs the full product)."""
+    import itertools
+    from multimodaltopicsegmentation_amd import AudioPortionDataset, TextSegmenter
+    g = torch.Generator().manual_seed(0)
+    docs = [(torch.randn(n, 48, generator=g), (torch.rand(n, generator=g) < 0.3).long().tolist(), f'{i}.npy') for i, n in enumerate([30, 12, 1, 22])]
+    docs2 = [(torch.randn(d[0].shape[0], 24, generator=g), d[1], d[2]) for d in docs]
+    crf = arch == 'biLSTMCRF'
+    ds = AudioPortionDataset(docs, {0: 0, 1: 1}, CRF=crf, truncate=False, second_input=docs2 if arch == 'BiLSTMLateFusion' else None)
+    batch = ds.collater([ds[i] for i in range(len(ds))])
+    batch = {k: (v.to(DEV) if isinstance(v, torch.Tensor) and k != 'src_lengths' else v) for k, v in batch.items()}
+    dims = [48, 24] if arch == 'BiLSTMLateFusion' else 48
+    losses = ['CrossEntropy'] if crf else ['CrossEntropy', 'BinaryCrossEntropy', 'FocalLoss']
+    for loss_fn, (opt, metric), (end_b, th) in itertools.product(losses, [('SGD', 'Pk'), ('Adam', 'WD'), ('Adam', 'F1')], [(False, None), (True, 0.5)]):
+        ts = TextSegmenter(2, dims, 25, num_layers=1, architecture=arch, loss_fn=loss_fn, optimizer=opt, metric=metric, end_boundary=end_b,
+                           threshold=th, nheads=4, attention_window=8).to(DEV)
+        o = ts.configure_optimizers()['optimizer']
+        first = None
+        for it in range(3):
+            o.zero_grad()
+            loss = ts.training_step(batch, it)
+            loss.backward()
+            o.step()
+            first = loss.item() if first is None else first
+        assert np.isfinite(loss.item()) and loss.item() <= first + 1e-3, (loss_fn, opt, first, loss.item())
+        assert ts.validation_step(batch, 0).item() >= 0
+        res = ts.test_step(batch, 0)
+        assert all(np.isfinite(float(v)) for v in res.values())
+        assert [len(t) for t in ts.predict_step(batch, 0)] == [30, 12, 1, 22]
