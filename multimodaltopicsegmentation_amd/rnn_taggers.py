@@ -122,6 +122,11 @@ class _RnnStack:
             g[off2:off2 + n2].copy_(g[off:off + n])
             off, n = lay.span(*self._names('weight_ih', k))
             ops.linear_wgrad(dxproj, S['hin'], g[off:off + n].view(8 * H, din))
+            # layer k's parameters (both directions: W_ih, W_hh, b_ih, b_hh are adjacent groups) are final: a data-parallel
+            # trainer may start reducing them while the lower layers' recurrences still run
+            a0 = lay.entries[self._names('weight_ih', k)[0]][0]
+            b0, bn = lay.span(*self._names('bias_hh', k))
+            o._grads_ready(a0, b0 + bn)
             if k > 0:
                 dprev = o._ws.get(f'{self.tag}dprev{k & 1}', N, din, dt, dev)
                 ops.linear_dgrad(dxproj, o._wspan(wf, *self._names('weight_ih', k), 8 * H, din), dprev)
@@ -129,6 +134,13 @@ class _RnnStack:
 
 
 class _RnnTaggerBase(_TaggerBase):
+    grad_hooks_cover_all = True      # every parameter span is announced through _grads_ready (trainer.NativeTrainer overlaps the exchange)
+
+    def _span_of(self, first, last):
+        a, _ = self._layout.entries[first]
+        b, n = self._layout.span(last, last)
+        return a, b + n
+
     def _check_rnn_args(self, dropout_in, dropout_out, LSTM, bidirectional):
         if dropout_in or dropout_out:
             raise NotImplementedError('dropout > 0 is not implemented in the HIP LSTM path (note the reference applies '
@@ -202,6 +214,7 @@ class BiLSTM(_RnnTaggerBase):
         if want_grad:
             g, lay = self.grad_flat(), self._layout
             ops.head_bwd_params(st['h'], dsc, lay.view(g, 'classification.weight'), lay.view(g, 'classification.bias'))
+            self._grads_ready(*self._span_of('classification.weight', 'classification.bias'))
             dout = self._ws.get('dout', B * Lq, 2 * self._hp, self.compute_dtype, dev)
             ops.head_bwd_data(dsc, self._w(self._flat, 'classification.weight'), dout)
             self._rnn.backward(st['saved'], dout, st['li32'], B, Lq)
@@ -275,6 +288,7 @@ class BiLSTMLateFusion(_RnnTaggerBase):
         if want_grad:
             g, lay = self.grad_flat(), self._layout
             ops.head_bwd_params(st['cat'], dsc, lay.view(g, 'classification.weight'), lay.view(g, 'classification.bias'))
+            self._grads_ready(*self._span_of('classification.weight', 'classification.bias'))
             dcat = self._ws.get('dcat', B * Lq, 4 * H, self.compute_dtype, dev)
             ops.head_bwd_data(dsc, self._w(self._flat, 'classification.weight'), dcat)
             d1 = self._ws.get('dout1', B * Lq, 2 * H, self.compute_dtype, dev)
@@ -353,6 +367,7 @@ class BiRnnCrf(_RnnTaggerBase):
                     dfe.view(B, Lq, C) if want_grad else None, lay.view(g, 'crf.transitions') if want_grad else None)
         if want_grad:
             ops.head_bwd_params(st['h'], dfe, lay.view(g, 'crf.fc.weight'), lay.view(g, 'crf.fc.bias'))
+            self._grads_ready(*self._span_of('crf.fc.weight', 'crf.transitions'))
             dout = self._ws.get('dout', B * Lq, 2 * self._hp, self.compute_dtype, dev)
             ops.head_bwd_data(dfe, self._w(self._flat, 'crf.fc.weight'), dout)
             self._rnn.backward(st['saved'], dout, st['li32'], B, Lq)

@@ -107,6 +107,7 @@ class _TaggerBase(FlatModule):
         return self._wcopy
 
     _grad_hook = None
+    grad_hooks_cover_all = False     # subclasses that announce every parameter span through _grads_ready set this
 
     def _grads_ready(self, a, b):
         """Flat-gradient span [a, b) is final for this step (hook installed by trainer.NativeTrainer for RCCL overlap)."""
@@ -170,6 +171,7 @@ class _NativeLoss(torch.autograd.Function):
 # =====================================================================================================
 class Transformer_segmenter(_TaggerBase):
     """models/CRF.py:508-610 with restricted=True: HF-Longformer-style local attention encoder + linear head."""
+    grad_hooks_cover_all = True
 
     def __init__(self, tagset_size, embedding_dim, hidden_dim, num_layers=6, nheads=8, dropout_in=0.0, dropout_out=0.0,
                  batch_first=True, loss_fn='CrossEntropy', positional_encoding=True, threshold=None, restricted=True,

@@ -99,7 +99,7 @@ class NativeTrainer:
         m = self.model
         x, lengths, tags = batch['src_tokens'], batch['src_lengths'], batch['tgt_tokens']
         self._last_L = x.shape[1]
-        overlapped = self.world > 1 and hasattr(m, '_grads_ready') and type(m).__name__ == 'Transformer_segmenter'
+        overlapped = self.world > 1 and getattr(m, 'grad_hooks_cover_all', False)
         self._pending = []
         m._grad_hook = self._on_grads_ready if overlapped else None
         if batch.get('src_tokens2') is not None and hasattr(m, '_rnn2'):
