@@ -343,10 +343,28 @@ class Transformer_segmenter(_TaggerBase):
         G = lambda name: lay.view(g, name)
         nl = len(self.radii)
         dh = None
+        # Weight-gradient GEMMs (MFMA-bound, needed by nobody until the optimizer) go to a side stream so that they overlap the
+        # HBM-bound kernels of the data-gradient chain (LayerNorm backward, band attention backward, GELU, reductions).  Off when
+        # a data-parallel hook is installed: the hook hands spans to RCCL in main-stream order.
+        side = self._side_stream(dev) if (self.overlap_wgrad and self._grad_hook is None and dev.type == 'cuda') else None
+        main = torch.cuda.current_stream(dev) if side is not None else None
+
+        def wgrad(dy, x, gview):
+            if side is None:
+                ops.linear_wgrad(dy, x, gview)
+                return
+            ev = torch.cuda.Event()
+            ev.record(main)                    # dy and x are complete on the main stream
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                ops.linear_wgrad(dy, x, gview)
+
         for li in range(nl - 1, -1, -1):
             lp = f'model.model.encoder.layer.{li}.'
             S = st['layers'][li]
             last = li == nl - 1
+            if side is not None:
+                main.wait_stream(side)         # the previous layer's weight gradients are done with ds2 / du / ds1 / dqkv
             ds2 = ws.get('ds2', N, D, dt, dev)
             if last:
                 ops.head_bwd_params(S['hout'], dscores, G('classification.weight'), G('classification.bias'))
@@ -354,13 +372,13 @@ class Transformer_segmenter(_TaggerBase):
                               G(lp + 'output.LayerNorm.weight'), G(lp + 'output.LayerNorm.bias'), dxsum=G(lp + 'output.dense.bias'),
                               dlogit=dscores if last else None, head_w=self._w(pf, 'classification.weight') if last else None)
             # FFN down:  s2 = f W2^T + b2 + a1
-            ops.linear_wgrad(ds2, S['f'], G(lp + 'output.dense.weight'))
+            wgrad(ds2, S['f'], G(lp + 'output.dense.weight'))
             du = ws.get('du', N, F, dt, dev)
             ops.linear_dgrad(ds2, self._w(wf, lp + 'output.dense.weight'), du)
             ops.gelu_bwd(S['u'], du)
             ops.colsum(du, G(lp + 'intermediate.dense.bias'))
             # FFN up:  u = a1 W1^T + b1 ;  da1 = ds2 (residual) + du W1
-            ops.linear_wgrad(du, S['a1'], G(lp + 'intermediate.dense.weight'))
+            wgrad(du, S['a1'], G(lp + 'intermediate.dense.weight'))
             da1 = ws.get('da1', N, D, dt, dev)
             ops.linear_dgrad(du, self._w(wf, lp + 'intermediate.dense.weight'), da1, residual=ds2)
             ds1 = ws.get('ds1', N, D, dt, dev)
@@ -368,7 +386,7 @@ class Transformer_segmenter(_TaggerBase):
                               G(lp + 'attention.output.LayerNorm.weight'), G(lp + 'attention.output.LayerNorm.bias'),
                               dxsum=G(lp + 'attention.output.dense.bias'))
             # attention output projection: s1 = ctx Wo^T + bo + hin
-            ops.linear_wgrad(ds1, S['ctx'], G(lp + 'attention.output.dense.weight'))
+            wgrad(ds1, S['ctx'], G(lp + 'attention.output.dense.weight'))
             # everything of this layer behind the q/k/v block (and the head, for the last layer) is final: let a
             # data-parallel trainer start reducing it while attention backward and the QKV GEMMs still run
             o0, _ = lay.entries[lp + 'attention.output.dense.weight']
@@ -383,7 +401,7 @@ class Transformer_segmenter(_TaggerBase):
             ops.band_attn_bwd(S['qkv'], st['lengths'], S['probs'], dctx, B, Lq, D, H, S['radius'], dqkv, dsc, dbias=g[off:off + n],
                               row0=st['pack']['row0'] if st['pack'] else None)
             off, n = lay.span(a_ + 'query.weight', a_ + 'value.weight')
-            ops.linear_wgrad(dqkv, S['hin'], g[off:off + n].view(3 * D, D))
+            wgrad(dqkv, S['hin'], g[off:off + n].view(3 * D, D))
             self._grads_ready(off, lay.entries[lp + 'attention.output.dense.weight'][0])    # q/k/v weights + biases
             dhin = ws.get(f'dhin{li & 1}', N, D, dt, dev)
             ops.linear_dgrad(dqkv, self._wspan(wf, a_ + 'query.weight', a_ + 'value.weight', 3 * D, D), dhin, residual=ds1)
@@ -399,9 +417,20 @@ class Transformer_segmenter(_TaggerBase):
                       lengths=st['lengths'])
         # embeddings: only the position rows a batch of this length can touch, then type row + LayerNorm
         D_ = self.embedding_dim
+        if side is not None:
+            main.wait_stream(side)             # every weight gradient has landed before the optimizer (or anyone else) looks
         p0 = lay.entries[e + 'position_embeddings.weight'][0]
         self._grads_ready(p0 + 2 * D_, p0 + (Lq + 2) * D_)
         self._grads_ready(lay.entries[e + 'token_type_embeddings.weight'][0], lay.entries['model.model.encoder.layer.0.attention.self.query.weight'][0])
+
+    overlap_wgrad = False    # True: +2 % step throughput at the BASELINE shape (2.70 -> 2.64 ms), but co-running kernels stretch each
+                             # other, so per-kernel timings (bench.py's roofline) stop describing a kernel; off by default
+
+    def _side_stream(self, dev):
+        s = getattr(self, '_wg_stream', None)
+        if s is None or s.device != dev:
+            s = self._wg_stream = torch.cuda.Stream(device=dev)
+        return s
 
     # ---- packed batches ---------------------------------------------------------------------------------
     pack_rows = 'auto'     # training path: 'auto' packs when >= 10 % of the B*L rows are padding; True / False force it
