@@ -240,6 +240,46 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
       return;
     }
   }
+  if constexpr (sizeof(TC) == 4) {
+    if (a.chain) {
+      // Split-K without slabs: the K-slices of a tile add their partial sums into C one after the other, slice 0 first.
+      // Workgroups are dispatched x-fastest, z-slowest, so slice z-1 of a tile was dispatched before slice z and always makes
+      // progress; by the time slice z has finished its own K range the wait is normally already over.  Hand-off = the
+      // agent-scope release/acquire recipe of the CDNA guide (plain C stores, one release fence + counter store by one lane;
+      // consumer polls relaxed, fences once, then plain loads).
+      const unsigned z = blockIdx.z;
+      unsigned* turn = a.chain + bid;
+      if (z > 0) {
+        if (tid == 0) {
+          while (__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != z) __builtin_amdgcn_s_sleep(16);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+      }
+      GemmArgs a3 = a;
+      a3.slab = nullptr;
+      if (z > 0) a3.epi |= MTS_EPI_ACCUM;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = bm0 + wm * 64 + i * 16 + r16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = bn0 + wn * 64 + j * 16 + 4 * g;
+          float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          epilogue4<bf16_t, TC>(a3, m, n, v, first_slice);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(turn, z + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = bm0 + wm * 64 + i * 16 + r16;
@@ -447,6 +487,8 @@ static int g_gemm_glds = -1;
 static int g_tile_mode = -1;
 static int g_force_splits = 0;
 static int g_tile_order = 1;
+static int g_chain = 0;          // "gemm_chain" = 1: split-K of the 128x128 kernel accumulates in place (no slabs, no reduce launch); measured
+                                 // SLOWER (532 vs 465 us on the QKV weight gradient: one agent-scope release per workgroup writes the L2 back)
 static int g_last_tile = 0, g_last_splits = 0;   // what the planner chose for the most recent bf16 mts_gemm (bench.py labels)
 
 extern "C" int mts_gemm_last_plan(int* tile, int* splits) {
@@ -462,6 +504,7 @@ extern "C" int mts_set_option(const char* key, int value) {
   if (!strcmp(key, "gemm_glds")) { g_gemm_glds = value; return MTS_OK; }
   if (!strcmp(key, "gemm_splits")) { g_force_splits = value; return MTS_OK; }
   if (!strcmp(key, "gemm_order")) { g_tile_order = value; return MTS_OK; }
+  if (!strcmp(key, "gemm_chain")) { g_chain = value; return MTS_OK; }
   if (!strcmp(key, "band_mfma")) { mts_band_set_mfma(value); return MTS_OK; }
   mts_set_error("mts_set_option: unknown key %s", key);
   return MTS_ERR_INVALID;
@@ -496,7 +539,7 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.residual = residual; a.aux = aux;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.ldaux = ldaux;
   a.epi = epilogue; a.colscale = colscale; a.ncols_scaled = ncols_scaled;
-  a.ksplit = K; a.slab = nullptr; a.order = g_tile_order;
+  a.ksplit = K; a.slab = nullptr; a.chain = nullptr; a.order = g_tile_order;
 
   if (a_dtype == MTS_F32) {
     StrideArgs s;
@@ -563,9 +606,18 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
   g_last_tile = use256 == 2 ? 224 : use256 == 1 ? 256 : 128;
   g_last_splits = splits;
   a.slab = nullptr;
+  bool chained = false;
   if (splits > 1) {
     a.ksplit = ceil_div(ceil_div(K, splits), BK) * BK;
-    a.slab = (float*)workspace;
+    chained = g_chain && !use256;
+    if (chained) {
+      const size_t nt128 = (size_t)ceil_div(M, BM) * ceil_div(N, BN);
+      a.chain = (unsigned*)workspace;
+      hipError_t e = hipMemsetAsync(workspace, 0, nt128 * sizeof(unsigned), st);
+      if (e != hipSuccess) { mts_set_error("mts_gemm: hipMemsetAsync: %s", hipGetErrorString(e)); return MTS_ERR_LAUNCH; }
+    } else {
+      a.slab = (float*)workspace;
+    }
   }
   if (use256) {
     int rc = use256 == 2 ? mts_launch_gemm224(a, layout, c_dtype == MTS_F32, splits, st) : mts_launch_gemm256(a, layout, c_dtype == MTS_F32, splits, st);
@@ -581,7 +633,7 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
     else if (layout == MTS_TT) launch_bf16<MTS_TT, bf16_t>(a, splits, st);
     else launch_bf16<MTS_TN, bf16_t>(a, splits, st);
   }
-  if (splits > 1)
+  if (splits > 1 && !chained)
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((size_t)M * (N / 4) + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
                        splits, M, N, (float*)C, ldc, (epilogue & MTS_EPI_ACCUM) ? 1 : 0);
   MTS_LAUNCH_CHECK("mts_gemm(bf16)");
