@@ -119,6 +119,14 @@ int mts_layernorm_bwd(void* stream, int dtype, int rows, int D, const void* x, c
 int mts_embed_bwd(void* stream, int dtype, int B, int L, int D, const void* dpre, float* dpos, int pos_offset,
                   const int32_t* row0, const int32_t* lengths);
 
+/* Inverted dropout: y = keep ? x / (1-p) : 0 (+ residual, if given), keep decided by a counter-based hash of (seed, element index)
+ * (F.dropout in RNN.forward, NeuralArchitectures.py:94,119 -- active even in eval mode there; nn.Dropout of the HF layers,
+ * modeling_longformer.py:424,1070,1129).  mask (optional, uint8 [n]) records keep = 1; x == y is allowed; n % 4 == 0.
+ * mts_dropout_bwd: dx = mask ? dy / (1-p) : 0 (dx == dy allowed). */
+int mts_dropout_fwd(void* stream, int dtype, size_t n, const void* x, const void* residual, void* y, uint8_t* mask,
+                    float p, uint64_t seed);
+int mts_dropout_bwd(void* stream, int dtype, size_t n, const void* dy, void* dx, const uint8_t* mask, float p);
+
 /* dy *= gelu_erf'(u) in place (FFN backward; modeling_longformer.py:1113-1116); n elements, n % 4 == 0 */
 int mts_gelu_bwd(void* stream, int dtype, size_t n, const void* u, void* dy);
 

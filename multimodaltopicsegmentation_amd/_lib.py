@@ -41,6 +41,8 @@ SIGNATURES = {
     'mts_layernorm_bwd_workspace': (_sz, [_i]),
     'mts_layernorm_bwd': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'mts_embed_bwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    'mts_dropout_fwd': (_i, [_vp, _i, _sz, _vp, _vp, _vp, _vp, _f, C.c_uint64]),
+    'mts_dropout_bwd': (_i, [_vp, _i, _sz, _vp, _vp, _vp, _f]),
     'mts_gelu_bwd': (_i, [_vp, _i, _sz, _vp, _vp]),
     'mts_band_slots': (_i, [_i]),
     'mts_band_attn_fwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

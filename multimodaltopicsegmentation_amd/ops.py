@@ -150,6 +150,15 @@ def embed_bwd(dpre, B, Lq, dpos, pos_offset, row0=None, lengths=None):
                             ptr(lengths) if row0 is not None else None))
 
 
+def dropout_fwd(x, y, p, seed, mask=None, residual=None):
+    """y = dropout(x) (+ residual); mask (uint8, same numel) records the kept elements for the backward."""
+    check(lib.mts_dropout_fwd(stream_ptr(), dtype_code(x.dtype), x.numel(), ptr(x), ptr(residual), ptr(y), ptr(mask), float(p), int(seed)))
+
+
+def dropout_bwd(dy, dx, mask, p):
+    check(lib.mts_dropout_bwd(stream_ptr(), dtype_code(dy.dtype), dy.numel(), ptr(dy), ptr(dx), ptr(mask), float(p)))
+
+
 def gelu_bwd(u, dy):
     check(lib.mts_gelu_bwd(stream_ptr(), dtype_code(u.dtype), u.numel(), ptr(u), ptr(dy)))
 

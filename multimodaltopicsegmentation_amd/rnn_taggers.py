@@ -142,9 +142,12 @@ class _RnnTaggerBase(_TaggerBase):
         return a, b + n
 
     def _check_rnn_args(self, dropout_in, dropout_out, LSTM, bidirectional):
-        if dropout_in or dropout_out:
-            raise NotImplementedError('dropout > 0 is not implemented in the HIP LSTM path (note the reference applies '
-                                      'F.dropout even in eval mode, NeuralArchitectures.py:94; it tests with dropout 0)')
+        for pr in (dropout_in, dropout_out):
+            if not 0.0 <= float(pr) < 1.0:
+                raise ValueError(f'dropout probability has to be between 0 and 1, but got {pr}')      # F.dropout's own check
+        # RNN.forward calls F.dropout(x, p) WITHOUT training=..., so the reference drops in eval mode too; same here
+        self.dropout_in, self.dropout_out = float(dropout_in), float(dropout_out)
+        self._drop_calls = 0
         if not LSTM:
             raise NotImplementedError('GRU (NeuralArchitectures.py:46-50) is listed as "next" in SURVEY.md §8f')
         if not bidirectional:
@@ -157,6 +160,29 @@ class _RnnTaggerBase(_TaggerBase):
         maxlen = min(maxlen, Lin)
         x = xs[:, :maxlen].contiguous()
         return x, maxlen
+
+    def _drop_seed(self):
+        """A fresh 64-bit seed per dropout call, derived from torch's seed (torch.manual_seed makes runs repeatable)."""
+        self._drop_calls += 1
+        return (torch.initial_seed() * 1000003 + self._drop_calls * 7919) & 0x7FFFFFFFFFFFFFFF
+
+    def _drop_in(self, xa, tag):
+        """F.dropout on the RNN input (NeuralArchitectures.py:94); no mask kept: nothing upstream needs a gradient."""
+        if not self.dropout_in:
+            return xa
+        out = self._ws.get('xdrop_' + tag, xa.shape[0], xa.shape[1], xa.dtype, xa.device)
+        ops.dropout_fwd(xa, out, self.dropout_in, self._drop_seed())
+        return out
+
+    def _drop_out(self, h, tag):
+        """F.dropout on the RNN output (NeuralArchitectures.py:119) -> (dropped copy, mask); `h` itself stays intact for the
+        recurrence backward."""
+        if not self.dropout_out:
+            return h, None
+        out = self._ws.get('hdrop_' + tag, h.shape[0], h.shape[1], h.dtype, h.device)
+        mask = self._ws.get('hmask_' + tag, h.shape[0], h.shape[1], torch.uint8, h.device)
+        ops.dropout_fwd(h, out, self.dropout_out, self._drop_seed(), mask=mask)
+        return out, mask
 
     def _to_act(self, x):
         x2 = x.reshape(-1, x.shape[-1])
@@ -195,10 +221,11 @@ class BiLSTM(_RnnTaggerBase):
         x, Lq = self._prep_input(xs, lengths)
         B = x.shape[0]
         li32 = self._prep_lengths(lengths, B, Lq, xs.device)
-        h, saved = self._rnn.forward(self._to_act(x), li32, B, Lq)
+        h, saved = self._rnn.forward(self._drop_in(self._to_act(x), 'r'), li32, B, Lq)
+        h, hmask = self._drop_out(h, 'r')
         scores = self._ws.get('scores', B * Lq, self.n_out, torch.float32, xs.device)
         ops.head_fwd(h, self._w(self._flat, 'classification.weight'), self._w(self._flat, 'classification.bias'), scores)
-        return dict(B=B, L=Lq, li32=li32, h=h, saved=saved, scores=scores.view(B, Lq, self.n_out))
+        return dict(B=B, L=Lq, li32=li32, h=h, hmask=hmask, saved=saved, scores=scores.view(B, Lq, self.n_out))
 
     def loss_and_grad(self, xs, lengths, tags, want_grad=True):
         L.require_gpu()
@@ -217,6 +244,8 @@ class BiLSTM(_RnnTaggerBase):
             self._grads_ready(*self._span_of('classification.weight', 'classification.bias'))
             dout = self._ws.get('dout', B * Lq, 2 * self._hp, self.compute_dtype, dev)
             ops.head_bwd_data(dsc, self._w(self._flat, 'classification.weight'), dout)
+            if st['hmask'] is not None:
+                ops.dropout_bwd(dout, dout, st['hmask'], self.dropout_out)
             self._rnn.backward(st['saved'], dout, st['li32'], B, Lq)
         return loss_out[0], st['scores']
 
@@ -268,14 +297,16 @@ class BiLSTMLateFusion(_RnnTaggerBase):
         xb, _ = self._prep_input(x2, lengths)
         B, H = xa.shape[0], self._hp
         li32 = self._prep_lengths(lengths, B, Lq, x1.device)
-        h1, s1 = self._rnn1.forward(self._to_act(xa), li32, B, Lq)
-        h2, s2 = self._rnn2.forward(self._to_act(xb), li32, B, Lq)
+        h1, s1 = self._rnn1.forward(self._drop_in(self._to_act(xa), 'r1'), li32, B, Lq)
+        h2, s2 = self._rnn2.forward(self._drop_in(self._to_act(xb), 'r2'), li32, B, Lq)
+        h1, m1 = self._drop_out(h1, 'r1')
+        h2, m2 = self._drop_out(h2, 'r2')
         cat = self._ws.get('cat', B * Lq, 4 * H, self.compute_dtype, x1.device)
         cat[:, :2 * H].copy_(h1)                       # torch.cat((x1, x2), axis=2), models/CRF.py:425
         cat[:, 2 * H:].copy_(h2)
         scores = self._ws.get('scores', B * Lq, self.n_out, torch.float32, x1.device)
         ops.head_fwd(cat, self._w(self._flat, 'classification.weight'), self._w(self._flat, 'classification.bias'), scores)
-        return dict(B=B, L=Lq, li32=li32, cat=cat, s1=s1, s2=s2, scores=scores.view(B, Lq, self.n_out))
+        return dict(B=B, L=Lq, li32=li32, cat=cat, s1=s1, s2=s2, m1=m1, m2=m2, scores=scores.view(B, Lq, self.n_out))
 
     def loss_and_grad(self, x1, x2, lengths, tags, want_grad=True):
         L.require_gpu()
@@ -295,6 +326,9 @@ class BiLSTMLateFusion(_RnnTaggerBase):
             d2 = self._ws.get('dout2', B * Lq, 2 * H, self.compute_dtype, dev)
             d1.copy_(dcat[:, :2 * H])
             d2.copy_(dcat[:, 2 * H:])
+            if st['m1'] is not None:
+                ops.dropout_bwd(d1, d1, st['m1'], self.dropout_out)
+                ops.dropout_bwd(d2, d2, st['m2'], self.dropout_out)
             self._rnn1.backward(st['s1'], d1, st['li32'], B, Lq)
             self._rnn2.backward(st['s2'], d2, st['li32'], B, Lq)
         return loss_out[0], st['scores']
@@ -350,10 +384,11 @@ class BiRnnCrf(_RnnTaggerBase):
         x, Lq = self._prep_input(xs, lengths)
         B = x.shape[0]
         li32 = self._prep_lengths(lengths, B, Lq, xs.device)
-        h, saved = self._rnn.forward(self._to_act(x), li32, B, Lq)
+        h, saved = self._rnn.forward(self._drop_in(self._to_act(x), 'r'), li32, B, Lq)
+        h, hmask = self._drop_out(h, 'r')
         feats = self._ws.get('feats', B * Lq, self.num_tags, torch.float32, xs.device)
         ops.head_fwd(h, self._w(self._flat, 'crf.fc.weight'), self._w(self._flat, 'crf.fc.bias'), feats)
-        return dict(B=B, L=Lq, li32=li32, h=h, saved=saved, feats=feats.view(B, Lq, self.num_tags))
+        return dict(B=B, L=Lq, li32=li32, h=h, hmask=hmask, saved=saved, feats=feats.view(B, Lq, self.num_tags))
 
     def loss_and_grad(self, xs, lengths, tags, want_grad=True):
         L.require_gpu()
@@ -370,6 +405,8 @@ class BiRnnCrf(_RnnTaggerBase):
             self._grads_ready(*self._span_of('crf.fc.weight', 'crf.transitions'))
             dout = self._ws.get('dout', B * Lq, 2 * self._hp, self.compute_dtype, dev)
             ops.head_bwd_data(dfe, self._w(self._flat, 'crf.fc.weight'), dout)
+            if st['hmask'] is not None:
+                ops.dropout_bwd(dout, dout, st['hmask'], self.dropout_out)
             self._rnn.backward(st['saved'], dout, st['li32'], B, Lq)
         return loss_out[0], st['feats']
 

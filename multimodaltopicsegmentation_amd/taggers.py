@@ -180,9 +180,15 @@ class Transformer_segmenter(_TaggerBase):
         self._init_common(loss_fn, threshold, alpha, gamma, compute_dtype)
         if not restricted:
             raise NotImplementedError('restricted=False (HF BertModel full attention, models/CRF.py:544) is outside the hot path')
-        if dropout_in or dropout_out:
-            raise NotImplementedError('dropout > 0 is not implemented in the HIP encoder yet (the reference evaluates with '
-                                      'dropout 0, train_fit.py:360-361)')
+        # dropout_in -> HF hidden_dropout_prob (embeddings, attention-output and FFN-output dense layers; training mode only),
+        # dropout_out -> attention_probs_dropout_prob (RestrictedTransformerLayer.py:88-89)
+        if not 0.0 <= float(dropout_in) < 1.0:
+            raise ValueError(f'dropout probability has to be between 0 and 1, but got {dropout_in}')
+        if dropout_out:
+            raise NotImplementedError('dropout on the attention probabilities (dropout_out > 0) is not implemented in the band '
+                                      'kernels; the reference evaluates with dropout 0 (train_fit.py:360-361)')
+        self.dropout_in = float(dropout_in)
+        self._drop_calls = 0
         self.embedding_dim, self.hidden_dim, self.tagset_size = embedding_dim, hidden_dim, tagset_size
         self.nheads, self.num_layers = nheads, num_layers
         # pyramidal windows, models/CRF.py:529; every entry must be even, RestrictedTransformerLayer.py:77-80
@@ -289,6 +295,11 @@ class Transformer_segmenter(_TaggerBase):
                                 lay.view(pf, e + 'token_type_embeddings.weight')[0], lay.view(pf, e + 'LayerNorm.weight'),
                                 lay.view(pf, e + 'LayerNorm.bias'), self.ln_eps, h, pre0, mean0, rstd0, row_src=row_src)
         st.update(pre0=pre0, mean0=mean0, rstd0=rstd0)
+        pdrop = self.dropout_in if self.training else 0.0          # nn.Dropout: training mode only
+        st['pdrop'] = pdrop
+        if pdrop:
+            st['m0'] = ws.get('dropmask0', N, D, torch.uint8, dev)
+            ops.dropout_fwd(h, h, pdrop, self._drop_seed(), mask=st['m0'])          # modeling_longformer.py:424
         scores = ws.get('scores', N, self.n_out, torch.float32, dev)
         scale = 1.0 / math.sqrt(D // H)
         for li, radius in enumerate(self.radii):
@@ -303,8 +314,15 @@ class Transformer_segmenter(_TaggerBase):
             probs = ws.get(f'probs{li}', N, H * slots, torch.float32, dev)
             ops.band_attn_fwd(qkv, lengths_i32, B, Lq, D, H, radius, ctx, probs, row0=row0)
             s1 = ws.get(f's1_{li}', N, D, dt, dev)
-            ops.linear_fwd(ctx, self._w(wf, lp + 'attention.output.dense.weight'), self._w(pf, lp + 'attention.output.dense.bias'),
-                           s1, residual=h)
+            m1 = m2 = None
+            if pdrop:                                              # dense -> dropout -> (+ input) -> LayerNorm, :1069-1072
+                tmp = ws.get('droptmp', N, D, dt, dev)
+                m1 = ws.get(f'dropmask1_{li}', N, D, torch.uint8, dev)
+                ops.linear_fwd(ctx, self._w(wf, lp + 'attention.output.dense.weight'), self._w(pf, lp + 'attention.output.dense.bias'), tmp)
+                ops.dropout_fwd(tmp, s1, pdrop, self._drop_seed(), mask=m1, residual=h)
+            else:
+                ops.linear_fwd(ctx, self._w(wf, lp + 'attention.output.dense.weight'), self._w(pf, lp + 'attention.output.dense.bias'),
+                               s1, residual=h)
             a1 = ws.get(f'a1_{li}', N, D, dt, dev)
             mean1 = ws.get(f'mean1_{li}', N, 1, torch.float32, dev)
             rstd1 = ws.get(f'rstd1_{li}', N, 1, torch.float32, dev)
@@ -315,7 +333,13 @@ class Transformer_segmenter(_TaggerBase):
             ops.linear_fwd(a1, self._w(wf, lp + 'intermediate.dense.weight'), self._w(pf, lp + 'intermediate.dense.bias'), f,
                            gelu=True, aux=u)
             s2 = ws.get(f's2_{li}', N, D, dt, dev)
-            ops.linear_fwd(f, self._w(wf, lp + 'output.dense.weight'), self._w(pf, lp + 'output.dense.bias'), s2, residual=a1)
+            if pdrop:                                              # :1128-1131
+                tmp = ws.get('droptmp', N, D, dt, dev)
+                m2 = ws.get(f'dropmask2_{li}', N, D, torch.uint8, dev)
+                ops.linear_fwd(f, self._w(wf, lp + 'output.dense.weight'), self._w(pf, lp + 'output.dense.bias'), tmp)
+                ops.dropout_fwd(tmp, s2, pdrop, self._drop_seed(), mask=m2, residual=a1)
+            else:
+                ops.linear_fwd(f, self._w(wf, lp + 'output.dense.weight'), self._w(pf, lp + 'output.dense.bias'), s2, residual=a1)
             hout = ws.get(f'hout{li}', N, D, dt, dev)
             mean2 = ws.get(f'mean2_{li}', N, 1, torch.float32, dev)
             rstd2 = ws.get(f'rstd2_{li}', N, 1, torch.float32, dev)
@@ -325,7 +349,7 @@ class Transformer_segmenter(_TaggerBase):
                               head_w=self._w(pf, 'classification.weight') if last else None,
                               head_b=self._w(pf, 'classification.bias') if last else None, scores=scores if last else None)
             st['layers'].append(dict(hin=h, qkv=qkv, ctx=ctx, probs=probs, s1=s1, a1=a1, mean1=mean1, rstd1=rstd1, u=u, f=f,
-                                     s2=s2, hout=hout, mean2=mean2, rstd2=rstd2, radius=radius, slots=slots))
+                                     s2=s2, hout=hout, mean2=mean2, rstd2=rstd2, radius=radius, slots=slots, m1=m1, m2=m2))
             h = hout
         st['scores'] = scores if pack else scores.view(B, Lq, self.n_out)
         st['hidden'] = h
@@ -371,10 +395,15 @@ class Transformer_segmenter(_TaggerBase):
             ops.layernorm_bwd(S['s2'], dh, self._w(pf, lp + 'output.LayerNorm.weight'), S['mean2'], S['rstd2'], ds2,
                               G(lp + 'output.LayerNorm.weight'), G(lp + 'output.LayerNorm.bias'), dxsum=G(lp + 'output.dense.bias'),
                               dlogit=dscores if last else None, head_w=self._w(pf, 'classification.weight') if last else None)
-            # FFN down:  s2 = f W2^T + b2 + a1
-            wgrad(ds2, S['f'], G(lp + 'output.dense.weight'))
+            # FFN down:  s2 = dropout(f W2^T + b2) + a1
+            ds2d = ds2
+            if st['pdrop']:
+                ds2d = ws.get('ds2d', N, D, dt, dev)               # gradient of the dense branch; the residual branch keeps ds2
+                ops.dropout_bwd(ds2, ds2d, S['m2'], st['pdrop'])
+                ops.colsum(ds2d, G(lp + 'output.dense.bias'))
+            wgrad(ds2d, S['f'], G(lp + 'output.dense.weight'))
             du = ws.get('du', N, F, dt, dev)
-            ops.linear_dgrad(ds2, self._w(wf, lp + 'output.dense.weight'), du)
+            ops.linear_dgrad(ds2d, self._w(wf, lp + 'output.dense.weight'), du)
             ops.gelu_bwd(S['u'], du)
             ops.colsum(du, G(lp + 'intermediate.dense.bias'))
             # FFN up:  u = a1 W1^T + b1 ;  da1 = ds2 (residual) + du W1
@@ -385,15 +414,20 @@ class Transformer_segmenter(_TaggerBase):
             ops.layernorm_bwd(S['s1'], da1, self._w(pf, lp + 'attention.output.LayerNorm.weight'), S['mean1'], S['rstd1'], ds1,
                               G(lp + 'attention.output.LayerNorm.weight'), G(lp + 'attention.output.LayerNorm.bias'),
                               dxsum=G(lp + 'attention.output.dense.bias'))
-            # attention output projection: s1 = ctx Wo^T + bo + hin
-            wgrad(ds1, S['ctx'], G(lp + 'attention.output.dense.weight'))
+            # attention output projection: s1 = dropout(ctx Wo^T + bo) + hin
+            ds1d = ds1
+            if st['pdrop']:
+                ds1d = ws.get('ds1d', N, D, dt, dev)
+                ops.dropout_bwd(ds1, ds1d, S['m1'], st['pdrop'])
+                ops.colsum(ds1d, G(lp + 'attention.output.dense.bias'))
+            wgrad(ds1d, S['ctx'], G(lp + 'attention.output.dense.weight'))
             # everything of this layer behind the q/k/v block (and the head, for the last layer) is final: let a
             # data-parallel trainer start reducing it while attention backward and the QKV GEMMs still run
             o0, _ = lay.entries[lp + 'attention.output.dense.weight']
             o1 = lay.entries[f'model.model.encoder.layer.{li + 1}.attention.self.query.weight'][0] if li + 1 < nl else g.numel()
             self._grads_ready(o0, o1)
             dctx = ws.get('dctx', N, D, dt, dev)
-            ops.linear_dgrad(ds1, self._w(wf, lp + 'attention.output.dense.weight'), dctx)
+            ops.linear_dgrad(ds1d, self._w(wf, lp + 'attention.output.dense.weight'), dctx)
             dqkv = ws.get('dqkv', N, 3 * D, dt, dev)
             dsc = ws.get('dsc', N, H * S['slots'], torch.float32, dev)
             a_ = lp + 'attention.self.'
@@ -407,6 +441,8 @@ class Transformer_segmenter(_TaggerBase):
             ops.linear_dgrad(dqkv, self._wspan(wf, a_ + 'query.weight', a_ + 'value.weight', 3 * D, D), dhin, residual=ds1)
             dh = dhin
         e = 'model.model.embeddings.'
+        if st['pdrop']:
+            ops.dropout_bwd(dh, dh, st['m0'], st['pdrop'])         # through the dropout behind the embedding LayerNorm
         dpre = ws.get('ds2', N, D, dt, dev)
         G(e + 'token_type_embeddings.weight').zero_()
         # d(type row 0) = sum over all rows of dpre = the LayerNorm backward's column sum of dx
@@ -422,6 +458,10 @@ class Transformer_segmenter(_TaggerBase):
         p0 = lay.entries[e + 'position_embeddings.weight'][0]
         self._grads_ready(p0 + 2 * D_, p0 + (Lq + 2) * D_)
         self._grads_ready(lay.entries[e + 'token_type_embeddings.weight'][0], lay.entries['model.model.encoder.layer.0.attention.self.query.weight'][0])
+
+    def _drop_seed(self):
+        self._drop_calls += 1
+        return (torch.initial_seed() * 1000003 + self._drop_calls * 7919) & 0x7FFFFFFFFFFFFFFF
 
     overlap_wgrad = False    # True: +2 % step throughput at the BASELINE shape (2.70 -> 2.64 ms), but co-running kernels stretch each
                              # other, so per-kernel timings (bench.py's roofline) stop describing a kernel; off by default
