@@ -148,10 +148,14 @@ int mts_gelu_bwd(void* stream, int dtype, size_t n, const void* u, void* dy);
  * qkv: [B*L, 3*D] act dtype, row = [q(D) | k(D) | v(D)], q already scaled; head h owns columns
  * h*hd..(h+1)*hd of each third.  lengths: int32 [B] (NULL = all L).  ctx: [B*L, D].
  * probs: fp32 [B*L, heads, slots] with slots = mts_band_slots(radius), saved for the backward.
+ * drop_p > 0: dropout on the attention probabilities (modeling_longformer.py:590; HF attention_probs_dropout_prob = the reference's
+ * dropout_out): what multiplies V is keep ? p / (1 - drop_p) : 0 with keep = hash(drop_seed, (row, head, slot)); `probs` stays whole
+ * and the backward, given the same drop_p / drop_seed, regenerates the mask.
  * ------------------------------------------------------------------------------------------- */
 int mts_band_slots(int radius);
 int mts_band_attn_fwd(void* stream, int dtype, int B, int L, int D, int heads, int radius,
-                      const void* qkv, const int32_t* lengths, void* ctx, float* probs, const int32_t* row0);
+                      const void* qkv, const int32_t* lengths, void* ctx, float* probs, const int32_t* row0,
+                      float drop_p, uint64_t drop_seed);
 /* dqkv [B*L, 3D] (dq already multiplied by q_scale so it is the gradient wrt the unscaled projection);
  * dscores: fp32 scratch of the same size as probs.  dbias (optional): fp32 [3D] column sums of dqkv as stored =
  * the gradient of the q/k/v biases (modeling_longformer.py:504-506), produced from the kernels' output tiles instead of
@@ -159,7 +163,8 @@ int mts_band_attn_fwd(void* stream, int dtype, int B, int L, int D, int heads, i
 size_t mts_band_attn_bwd_workspace(int B, int L, int D);
 int mts_band_attn_bwd(void* stream, int dtype, int B, int L, int D, int heads, int radius, float q_scale,
                       const void* qkv, const int32_t* lengths, const float* probs, const void* dctx,
-                      void* dqkv, float* dscores, float* dbias, void* workspace, const int32_t* row0, int n_rows);
+                      void* dqkv, float* dscores, float* dbias, void* workspace, const int32_t* row0, int n_rows,
+                      float drop_p, uint64_t drop_seed);
 
 /* ---------------------------------------------------------------------------------------------
  * Tagger head tail: loss + its gradient, and greedy decode.

@@ -45,9 +45,9 @@ SIGNATURES = {
     'mts_dropout_bwd': (_i, [_vp, _i, _sz, _vp, _vp, _vp, _f]),
     'mts_gelu_bwd': (_i, [_vp, _i, _sz, _vp, _vp]),
     'mts_band_slots': (_i, [_i]),
-    'mts_band_attn_fwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'mts_band_attn_fwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, C.c_uint64]),
     'mts_band_attn_bwd_workspace': (_sz, [_i, _i, _i]),
-    'mts_band_attn_bwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
+    'mts_band_attn_bwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, C.c_uint64]),
     'mts_tagger_loss_workspace': (_sz, [_i, _i]),
     'mts_tagger_loss': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _sz, _vp, _i]),
     'mts_greedy_decode': (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp]),

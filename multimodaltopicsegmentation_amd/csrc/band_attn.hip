@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256) void band_fwd_kernel(const BandArgs a) {
     float* prow = a.probs + ((size_t)(doc.base + i) * a.heads + h) * a.slots;
     for (int c = g; c < a.slots; c += 8) {
       const float p = Ps[tq * a.ps + c] * inv;
-      Ps[tq * a.ps + c] = p;
+      // dropout (modeling_longformer.py:590) acts on what multiplies V; the saved probabilities stay whole
+      Ps[tq * a.ps + c] = (a.drop_thr && !band_keep(a, doc.base + i, h, c)) ? 0.f : (a.drop_thr ? p * a.drop_scale : p);
       if (i < doc.Lb) prow[c] = p;
     }
   }
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(256) void band_bwd_q_kernel(const BandArgs a) {
     for (int t = 0; t < 4; ++t) {
       const int c = 32 * sb + g + 8 * t;
       const float p = (i < doc.Lb) ? prow[c] : 0.f;      // zero for masked keys / queries and for c >= W
+      if (a.drop_thr) s[t] = band_keep(a, doc.base + i, h, c) ? s[t] * a.drop_scale : 0.f;      // gradient through the dropout
       Ps[tq * a.ps + c] = s[t];
       delta += p * s[t];
     }
@@ -260,11 +262,15 @@ __global__ __launch_bounds__(256) void band_bwd_q_kernel(const BandArgs a) {
 // coefficient is X[i][2w - c'] with X = dS (for dK) or P (for dV).
 // ------------------------------------------------------------------------------------------------
 // raw[r][cidx] = X[row i = first_i + r][slot cbase + cidx], 32 slots wide, zero outside the valid ranges
-__device__ __forceinline__ void stage_coef(float* raw, const float* __restrict__ X, size_t row_stride, int first_i, int L, int cbase, int W) {
+__device__ __forceinline__ void stage_coef(float* raw, const float* __restrict__ X, size_t row_stride, int first_i, int L, int cbase, int W,
+                                           const BandArgs& a, int base_row, int h, bool dropped) {
   for (int idx = threadIdx.x; idx < KV_ROWS * 32; idx += 256) {
     const int r = idx >> 5, ci = idx & 31;
     const int i = first_i + r, c = cbase + ci;
-    raw[idx] = (i >= 0 && i < L && c >= 0 && c < W) ? X[(size_t)i * row_stride + c] : 0.f;
+    const bool ok = (i >= 0 && i < L && c >= 0 && c < W);
+    float x = ok ? X[(size_t)i * row_stride + c] : 0.f;
+    if (dropped && ok) x = band_keep(a, base_row + i, h, c) ? x * a.drop_scale : 0.f;     // dV sees the dropped probabilities
+    raw[idx] = x;
   }
 }
 
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(256) void band_bwd_kv_kernel(const BandArgs a) {
     const int ncc = min(32, W - 32 * sb);
     for (int pass = 0; pass < 2; ++pass) {
       __syncthreads();
-      stage_coef(raw, pass == 0 ? dsb : pb, xrow, first_i, doc.Lb, cbase, W);
+      stage_coef(raw, pass == 0 ? dsb : pb, xrow, first_i, doc.Lb, cbase, W, a, doc.base, h, pass == 1 && a.drop_thr != 0);
       if (pass == 0) stage_rows<T>(Rs, a.rs, qbase, ld, first_i, KV_ROWS, doc.Lb, hd);          // scaled q rows
       else stage_rows<T>(Rs, a.rs, dcbase, a.D, first_i, KV_ROWS, doc.Lb, hd);                  // dCtx rows
       __syncthreads();
@@ -350,7 +356,18 @@ static int band_fill(BandArgs& a, int dtype, int B, int L, int D, int heads, int
   a.ps = a.slots + 1;
   a.q_scale = 1.f;
   a.bias_slab = nullptr; a.img_bytes = 0; a.row0 = nullptr;
+  a.drop_scale = 1.f; a.drop_thr = 0; a.drop_seed = 0;
   a.lengths = nullptr; a.qkv = nullptr; a.ctx = nullptr; a.probs = nullptr; a.dctx = nullptr; a.dqkv = nullptr; a.dscores = nullptr;
+  return MTS_OK;
+}
+
+static int band_set_dropout(BandArgs& a, float p, uint64_t seed, const char* who) {
+  MTS_CHECK_ARG(p >= 0.f && p < 1.f, "%s: dropout probability has to be between 0 and 1, but got %f", who, (double)p);
+  if (p > 0.f) {
+    a.drop_thr = (uint32_t)std::max<double>(1.0, std::min<double>(4294967295.0, (double)p * 4294967296.0));
+    a.drop_scale = 1.0f / (1.0f - p);
+    a.drop_seed = seed;
+  }
   return MTS_OK;
 }
 
@@ -376,13 +393,15 @@ static int band_fwd_launch(const BandArgs& a, hipStream_t st) {
 }
 
 extern "C" int mts_band_attn_fwd(void* stream, int dtype, int B, int L, int D, int heads, int radius, const void* qkv, const int32_t* lengths,
-                                 void* ctx, float* probs, const int32_t* row0) {
+                                 void* ctx, float* probs, const int32_t* row0, float drop_p, uint64_t drop_seed) {
   BandArgs a;
   int rc = band_fill(a, dtype, B, L, D, heads, radius, "mts_band_attn_fwd");
   if (rc) return rc;
   MTS_CHECK_ARG(qkv && ctx && probs, "mts_band_attn_fwd: null pointer");
   MTS_CHECK_ARG(!row0 || lengths, "mts_band_attn_fwd: packed rows (row0) need lengths");
   a.row0 = row0;
+  rc = band_set_dropout(a, drop_p, drop_seed, "mts_band_attn_fwd");
+  if (rc) return rc;
   a.qkv = qkv; a.lengths = lengths; a.ctx = ctx; a.probs = probs;
   if (dtype == MTS_BF16 && g_band_mfma) {
     rc = mts_band_mfma_fwd(a, (hipStream_t)stream);
@@ -422,7 +441,7 @@ extern "C" size_t mts_band_attn_bwd_workspace(int B, int L, int D) {
 
 extern "C" int mts_band_attn_bwd(void* stream, int dtype, int B, int L, int D, int heads, int radius, float q_scale, const void* qkv,
                                  const int32_t* lengths, const float* probs, const void* dctx, void* dqkv, float* dscores, float* dbias,
-                                 void* workspace, const int32_t* row0, int n_rows) {
+                                 void* workspace, const int32_t* row0, int n_rows, float drop_p, uint64_t drop_seed) {
   BandArgs a;
   int rc = band_fill(a, dtype, B, L, D, heads, radius, "mts_band_attn_bwd");
   if (rc) return rc;
@@ -430,6 +449,8 @@ extern "C" int mts_band_attn_bwd(void* stream, int dtype, int B, int L, int D, i
   MTS_CHECK_ARG(!dbias || workspace, "mts_band_attn_bwd: dbias needs mts_band_attn_bwd_workspace() bytes of workspace");
   MTS_CHECK_ARG(!row0 || (lengths && n_rows > 0 && n_rows <= B * L), "mts_band_attn_bwd: packed rows (row0) need lengths and 0 < n_rows <= B*L");
   a.row0 = row0;
+  rc = band_set_dropout(a, drop_p, drop_seed, "mts_band_attn_bwd");
+  if (rc) return rc;
   a.qkv = qkv; a.lengths = lengths; a.probs = const_cast<float*>(probs); a.dctx = dctx; a.dqkv = dqkv; a.dscores = dscores;
   a.q_scale = q_scale;
   if (dtype == MTS_BF16 && g_band_mfma) {

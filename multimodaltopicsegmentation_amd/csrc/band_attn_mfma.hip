@@ -218,7 +218,15 @@ __global__ __launch_bounds__(256, OCC) void band_mfma_fwd_kernel(const BandArgs 
     for (int s = 0; s < NKB / 2; ++s) {
       bf16x8 c8;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { c8[r] = (bf16_t)pr[2 * s][qb][r]; c8[4 + r] = (bf16_t)pr[2 * s + 1][qb][r]; }
+      for (int r = 0; r < 4; ++r) {
+        float p0 = pr[2 * s][qb][r], p1 = pr[2 * s + 1][qb][r];
+        if (a.drop_thr) {                                  // dropout acts on what multiplies V; the saved probabilities stay whole
+          const int c0 = 16 * (2 * s) + 4 * g + r - 16 * qb - l15;
+          p0 = band_keep(a, doc.base + i, h, c0) ? p0 * a.drop_scale : 0.f;
+          p1 = band_keep(a, doc.base + i, h, c0 + 16) ? p1 * a.drop_scale : 0.f;
+        }
+        c8[r] = (bf16_t)p0; c8[4 + r] = (bf16_t)p1;
+      }
       coef[s][qb] = c8;
     }
   }
@@ -292,6 +300,16 @@ __global__ __launch_bounds__(256, OCC) void band_mfma_bwd_q_kernel(const BandArg
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     float delta = 0.f;
+    if (a.drop_thr) {                                      // gradient through the dropout: dP = keep ? dP_dropped / (1-p) : 0
+      const int i = q0 + 16 * qb + l15;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * kb + 4 * g + r - 16 * qb - l15;
+          acc[kb][qb][r] = band_keep(a, doc.base + i, h, c) ? acc[kb][qb][r] * a.drop_scale : 0.f;
+        }
+    }
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -342,7 +360,7 @@ __global__ __launch_bounds__(256, OCC) void band_mfma_bwd_q_kernel(const BandArg
 // ------------------------------------------------------------------------------------------------
 template <int NS>
 __device__ __forceinline__ void load_coef_T(const float* __restrict__ X, size_t row_stride, int ibase, int j0, int w, int W, int L, int lane,
-                                            bf16x8 (&coef)[NS][2]) {
+                                            bf16x8 (&coef)[NS][2], const BandArgs& a, int base_row, int h, bool dropped) {
   const int l15 = lane & 15, g = lane >> 4;
   float v[NS][2][8];
 #pragma unroll
@@ -354,7 +372,9 @@ __device__ __forceinline__ void load_coef_T(const float* __restrict__ X, size_t 
       for (int e = 0; e < 8; ++e) {
         const int i = ibase + 32 * s + 8 * g + e, c = j - i + w;
         const bool ok = i >= 0 && i < L && j < L && c >= 0 && c < W;
-        v[s][nb][e] = ok ? X[(size_t)i * row_stride + c] : 0.f;
+        float x = ok ? X[(size_t)i * row_stride + c] : 0.f;
+        if (dropped && ok) x = band_keep(a, base_row + i, h, c) ? x * a.drop_scale : 0.f;        // dV sees the dropped probabilities
+        v[s][nb][e] = x;
       }
     }
 #pragma unroll
@@ -402,7 +422,7 @@ __global__ __launch_bounds__(256, OCC) void band_mfma_bwd_kv_kernel(const BandAr
   f32x4 o[2 * KK][2];
 
   stage_dma<KK>(img, dcbase, a.D, t0 - w, nrows, L);                                  // dCtx rows
-  load_coef_T<NS>(pb, xrow, j0 - w, j0, w, W, L, lane, coef);
+  load_coef_T<NS>(pb, xrow, j0 - w, j0, w, W, L, lane, coef, a, doc.base, h, a.drop_thr != 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   zero_acc<2 * KK>(o);
@@ -414,7 +434,7 @@ __global__ __launch_bounds__(256, OCC) void band_mfma_bwd_kv_kernel(const BandAr
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();                                                                    // every wave is done with the dCtx image
   stage_dma<KK>(img, qbase, ld, t0 - w, nrows, L);                                    // (scaled) q rows
-  load_coef_T<NS>(dsb, xrow, j0 - w, j0, w, W, L, lane, coef);
+  load_coef_T<NS>(dsb, xrow, j0 - w, j0, w, W, L, lane, coef, a, doc.base, h, false);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   zero_acc<2 * KK>(o);

@@ -11,6 +11,7 @@ struct BandArgs {
   int ps;      // LDS row stride (floats) of the probability tile
   float q_scale;
   const int32_t* row0;  // packed batches: first row of document b (rows of a document are contiguous, only its `lengths[b]` valid rows exist); NULL = padded [B, L]
+  float drop_scale; uint32_t drop_thr; uint64_t drop_seed;   // dropout on the attention probabilities (drop_thr = 0: off)
   float* bias_slab;   // MFMA backward: per-(document, 128-row tile) column sums of dqkv, [B*ceil(L/128)][3D], or NULL
   int img_bytes;      // MFMA kernels: size of the staged-row LDS image
 };
@@ -33,6 +34,11 @@ struct DocView { int base; int Lb; };
 __device__ __forceinline__ DocView doc_view(const BandArgs& a, int b) {
   if (a.row0) return DocView{a.row0[b], min(a.lengths[b], a.L)};
   return DocView{b * a.L, a.L};
+}
+
+// attention-probability dropout (modeling_longformer.py:590): keep decision of probability (packed row, head, slot)
+__device__ __forceinline__ bool band_keep(const BandArgs& a, int grow, int h, int c) {
+  return mts_hash32(a.drop_seed, ((uint64_t)grow * a.heads + h) * a.slots + c) >= a.drop_thr;
 }
 
 // band_attn_mfma.hip: returns MTS_OK after launching, or -1 when the shape is outside what the MFMA kernels cover

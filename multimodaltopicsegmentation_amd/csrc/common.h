@@ -128,5 +128,14 @@ __device__ __forceinline__ float gelu_erf_grad_f(float x) {
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// keep/drop decision of the dropout kernels: counter-based (no state), reproducible on the host
+__host__ __device__ inline uint32_t mts_hash32(uint64_t seed, uint64_t idx) {   // splitmix64 finaliser
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }

@@ -167,21 +167,21 @@ def band_slots(radius):
     return lib.mts_band_slots(radius)
 
 
-def band_attn_fwd(qkv, lengths, B, Lq, D, heads, radius, ctx, probs, row0=None):
+def band_attn_fwd(qkv, lengths, B, Lq, D, heads, radius, ctx, probs, row0=None, drop_p=0.0, drop_seed=0):
     """row0 (int32 [B], optional): packed batch -- document b owns rows row0[b] .. row0[b] + lengths[b] - 1 of qkv / ctx / probs."""
     with _timed(('band_fwd', B, Lq, D, heads, radius)):
         check(lib.mts_band_attn_fwd(stream_ptr(), dtype_code(qkv.dtype), B, Lq, D, heads, radius, ptr(qkv), ptr(lengths), ptr(ctx), ptr(probs),
-                                    ptr(row0)))
+                                    ptr(row0), float(drop_p), int(drop_seed)))
 
 
-def band_attn_bwd(qkv, lengths, probs, dctx, B, Lq, D, heads, radius, dqkv, dscores, dbias=None, row0=None):
+def band_attn_bwd(qkv, lengths, probs, dctx, B, Lq, D, heads, radius, dqkv, dscores, dbias=None, row0=None, drop_p=0.0, drop_seed=0):
     """dbias (fp32 [3D], optional): column sums of dqkv = q/k/v bias gradients, fused into the kernels' output stage."""
     q_scale = 1.0 / math.sqrt(D // heads)
     ws = _scratch(lib.mts_band_attn_bwd_workspace(B, Lq, D), qkv.device, 'band_bwd') if dbias is not None else None
     with _timed(('band_bwd', B, Lq, D, heads, radius)):
         check(lib.mts_band_attn_bwd(stream_ptr(), dtype_code(qkv.dtype), B, Lq, D, heads, radius, q_scale, ptr(qkv), ptr(lengths),
                                     ptr(probs), ptr(dctx), ptr(dqkv), ptr(dscores), ptr(dbias), ptr(ws), ptr(row0),
-                                    qkv.shape[0] if row0 is not None else 0))
+                                    qkv.shape[0] if row0 is not None else 0, float(drop_p), int(drop_seed)))
 
 
 def tagger_loss(kind, scores, targets, lengths, alpha, gamma, loss_out, dscores, row_src=None, batch_shape=None):

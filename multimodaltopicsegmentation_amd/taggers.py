@@ -184,10 +184,9 @@ class Transformer_segmenter(_TaggerBase):
         # dropout_out -> attention_probs_dropout_prob (RestrictedTransformerLayer.py:88-89)
         if not 0.0 <= float(dropout_in) < 1.0:
             raise ValueError(f'dropout probability has to be between 0 and 1, but got {dropout_in}')
-        if dropout_out:
-            raise NotImplementedError('dropout on the attention probabilities (dropout_out > 0) is not implemented in the band '
-                                      'kernels; the reference evaluates with dropout 0 (train_fit.py:360-361)')
-        self.dropout_in = float(dropout_in)
+        if not 0.0 <= float(dropout_out) < 1.0:
+            raise ValueError(f'dropout probability has to be between 0 and 1, but got {dropout_out}')
+        self.dropout_in, self.dropout_out = float(dropout_in), float(dropout_out)
         self._drop_calls = 0
         self.embedding_dim, self.hidden_dim, self.tagset_size = embedding_dim, hidden_dim, tagset_size
         self.nheads, self.num_layers = nheads, num_layers
@@ -312,7 +311,9 @@ class Transformer_segmenter(_TaggerBase):
             ops.linear_fwd(h, wqkv, bqkv, qkv, colscale=scale, ncols_scaled=D)
             ctx = ws.get(f'ctx{li}', N, D, dt, dev)
             probs = ws.get(f'probs{li}', N, H * slots, torch.float32, dev)
-            ops.band_attn_fwd(qkv, lengths_i32, B, Lq, D, H, radius, ctx, probs, row0=row0)
+            pattn = self.dropout_out if self.training else 0.0     # attention_probs_dropout_prob, modeling_longformer.py:590
+            aseed = self._drop_seed() if pattn else 0
+            ops.band_attn_fwd(qkv, lengths_i32, B, Lq, D, H, radius, ctx, probs, row0=row0, drop_p=pattn, drop_seed=aseed)
             s1 = ws.get(f's1_{li}', N, D, dt, dev)
             m1 = m2 = None
             if pdrop:                                              # dense -> dropout -> (+ input) -> LayerNorm, :1069-1072
@@ -349,7 +350,8 @@ class Transformer_segmenter(_TaggerBase):
                               head_w=self._w(pf, 'classification.weight') if last else None,
                               head_b=self._w(pf, 'classification.bias') if last else None, scores=scores if last else None)
             st['layers'].append(dict(hin=h, qkv=qkv, ctx=ctx, probs=probs, s1=s1, a1=a1, mean1=mean1, rstd1=rstd1, u=u, f=f,
-                                     s2=s2, hout=hout, mean2=mean2, rstd2=rstd2, radius=radius, slots=slots, m1=m1, m2=m2))
+                                     s2=s2, hout=hout, mean2=mean2, rstd2=rstd2, radius=radius, slots=slots, m1=m1, m2=m2,
+                                     pattn=pattn, aseed=aseed))
             h = hout
         st['scores'] = scores if pack else scores.view(B, Lq, self.n_out)
         st['hidden'] = h
@@ -433,7 +435,7 @@ class Transformer_segmenter(_TaggerBase):
             a_ = lp + 'attention.self.'
             off, n = lay.span(a_ + 'query.bias', a_ + 'value.bias')
             ops.band_attn_bwd(S['qkv'], st['lengths'], S['probs'], dctx, B, Lq, D, H, S['radius'], dqkv, dsc, dbias=g[off:off + n],
-                              row0=st['pack']['row0'] if st['pack'] else None)
+                              row0=st['pack']['row0'] if st['pack'] else None, drop_p=S['pattn'], drop_seed=S['aseed'])
             off, n = lay.span(a_ + 'query.weight', a_ + 'value.weight')
             wgrad(dqkv, S['hin'], g[off:off + n].view(3 * D, D))
             self._grads_ready(off, lay.entries[lp + 'attention.output.dense.weight'][0])    # q/k/v weights + biases

@@ -99,7 +99,7 @@ def test_transformer_hidden_dropout():
     lengths = torch.tensor([40, 22, 5])
     g = torch.Generator().manual_seed(8)
     ts = TextSegmenter(2, D, 24, num_layers=2, architecture='Transformer', loss_fn='FocalLoss', nheads=4, attention_window=8, dropout_in=0.25,
-                       compute_dtype='fp32').to(DEV)
+                       dropout_out=0.2, compute_dtype='fp32').to(DEV)
     m = ts.model
     x = torch.randn(B, L, D, generator=g).to(DEV)
     y = (torch.rand(B, L, generator=g) < 0.3).float().to(DEV)
@@ -113,5 +113,37 @@ def test_transformer_hidden_dropout():
     ref.model.load_state_dict(m.state_dict())
     ref.model.eval()
     assert torch.equal(m(x, lengths)[0], ref.model(x, lengths)[0])
-    with pytest.raises(NotImplementedError):
-        TextSegmenter(2, D, 24, architecture='Transformer', nheads=4, attention_window=8, dropout_out=0.1)
+    with pytest.raises(ValueError):
+        TextSegmenter(2, D, 24, architecture='Transformer', nheads=4, attention_window=8, dropout_out=1.5)
+
+
+def test_attention_dropout_matrix_core_kernels_match_generic_ones():
+    """bf16, head dim 32: the MFMA band kernels and the generic ones regenerate the same mask from (seed, row, head, slot)."""
+    import math
+    from multimodaltopicsegmentation_amd import _lib as L, ops
+    B, Lq, D, heads, radius, p, seed = 2, 150, 128, 4, 15, 0.3, 99
+    g = torch.Generator().manual_seed(5)
+    qkv = (torch.randn(B * Lq, 3 * D, generator=g) * 0.7).to(torch.bfloat16).to(DEV)
+    dctx = torch.randn(B * Lq, D, generator=g).to(torch.bfloat16).to(DEV)
+    lens = torch.tensor([150, 77], dtype=torch.int32, device=DEV)
+    slots = ops.band_slots(radius)
+    out = {}
+    try:
+        for mode in (1, 0):
+            L.check(L.lib.mts_set_option(b'band_mfma', mode))
+            ctx = torch.empty(B * Lq, D, dtype=torch.bfloat16, device=DEV)
+            probs = torch.empty(B * Lq, heads * slots, device=DEV)
+            ops.band_attn_fwd(qkv, lens, B, Lq, D, heads, radius, ctx, probs, drop_p=p, drop_seed=seed)
+            dqkv = torch.empty(B * Lq, 3 * D, dtype=torch.bfloat16, device=DEV)
+            dsc = torch.empty_like(probs)
+            ops.band_attn_bwd(qkv, lens, probs, dctx, B, Lq, D, heads, radius, dqkv, dsc, drop_p=p, drop_seed=seed)
+            ctx0 = torch.empty_like(ctx)
+            ops.band_attn_fwd(qkv, lens, B, Lq, D, heads, radius, ctx0, torch.empty_like(probs))
+            out[mode] = (ctx.float().cpu(), dqkv.float().cpu(), probs.cpu(), ctx0.float().cpu())
+    finally:
+        L.check(L.lib.mts_set_option(b'band_mfma', 1))
+    for a, b in zip(out[1][:3], out[0][:3]):
+        assert float((a - b).abs().max()) <= 3e-2 * max(1.0, float(b.abs().max()))
+    assert float((out[1][0] - out[1][3]).abs().max()) > 0.05        # dropout really changed the context rows
+    rs = out[1][2].view(B, Lq, heads, slots).sum(-1)
+    assert float((rs[0] - 1).abs().max()) < 1e-5                     # the saved probabilities are the un-dropped ones
