@@ -46,7 +46,8 @@ class _timed:
 
 def _scratch(nbytes, device, tag):
     """Grow-only scratch buffers keyed by (device, tag): never reallocated inside a steady-state step."""
-    key = (str(device), tag)
+    # one buffer per (device, purpose, HIP stream): kernels launched on different streams may run concurrently
+    key = (str(device), tag, torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == 'cuda' else 0)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)

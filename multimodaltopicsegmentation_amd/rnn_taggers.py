@@ -269,6 +269,13 @@ class BiLSTM(_RnnTaggerBase):
 
 class BiLSTMLateFusion(_RnnTaggerBase):
     """models/CRF.py:371-479: two independent RNNs, plain concat (there is no gate in the reference), one head."""
+    concurrent_encoders = True       # model1 / model2 on two HIP streams (bitwise the same results; off under a data-parallel hook)
+
+    def _side_stream(self, dev):
+        s = getattr(self, '_enc_stream', None)
+        if s is None or s.device != dev:
+            s = self._enc_stream = torch.cuda.Stream(device=dev)
+        return s
 
     def __init__(self, tagset_size, embedding_dim, hidden_dim, num_layers=1, bidirectional=True, dropout_in=0.0, dropout_out=0.0,
                  batch_first=True, LSTM=True, loss_fn='CrossEntropy', threshold=None, device=None, alpha=0.9, gamma=2,
@@ -297,8 +304,18 @@ class BiLSTMLateFusion(_RnnTaggerBase):
         xb, _ = self._prep_input(x2, lengths)
         B, H = xa.shape[0], self._hp
         li32 = self._prep_lengths(lengths, B, Lq, x1.device)
-        h1, s1 = self._rnn1.forward(self._drop_in(self._to_act(xa), 'r1'), li32, B, Lq)
-        h2, s2 = self._rnn2.forward(self._drop_in(self._to_act(xb), 'r2'), li32, B, Lq)
+        # the two encoders are independent and each recurrence occupies a few dozen CUs: run the second one on a side stream
+        side = self._side_stream(x1.device) if (self.concurrent_encoders and self._grad_hook is None) else None
+        if side is not None:
+            main = torch.cuda.current_stream(x1.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                h2, s2 = self._rnn2.forward(self._drop_in(self._to_act(xb), 'r2'), li32, B, Lq)
+            h1, s1 = self._rnn1.forward(self._drop_in(self._to_act(xa), 'r1'), li32, B, Lq)
+            main.wait_stream(side)
+        else:
+            h1, s1 = self._rnn1.forward(self._drop_in(self._to_act(xa), 'r1'), li32, B, Lq)
+            h2, s2 = self._rnn2.forward(self._drop_in(self._to_act(xb), 'r2'), li32, B, Lq)
         h1, m1 = self._drop_out(h1, 'r1')
         h2, m2 = self._drop_out(h2, 'r2')
         cat = self._ws.get('cat', B * Lq, 4 * H, self.compute_dtype, x1.device)
@@ -329,8 +346,17 @@ class BiLSTMLateFusion(_RnnTaggerBase):
             if st['m1'] is not None:
                 ops.dropout_bwd(d1, d1, st['m1'], self.dropout_out)
                 ops.dropout_bwd(d2, d2, st['m2'], self.dropout_out)
-            self._rnn1.backward(st['s1'], d1, st['li32'], B, Lq)
-            self._rnn2.backward(st['s2'], d2, st['li32'], B, Lq)
+            side = self._side_stream(dev) if (self.concurrent_encoders and self._grad_hook is None) else None
+            if side is not None:
+                main = torch.cuda.current_stream(dev)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._rnn2.backward(st['s2'], d2, st['li32'], B, Lq)
+                self._rnn1.backward(st['s1'], d1, st['li32'], B, Lq)
+                main.wait_stream(side)
+            else:
+                self._rnn1.backward(st['s1'], d1, st['li32'], B, Lq)
+                self._rnn2.backward(st['s2'], d2, st['li32'], B, Lq)
         return loss_out[0], st['scores']
 
     def loss(self, x1, x2, lengths, tags, segments=None):
