@@ -29,6 +29,18 @@ except Exception:  # noqa: BLE001
             self._last_logged = getattr(self, '_last_logged', {})
             self._last_logged.update(d)
 
+        @classmethod
+        def load_from_checkpoint(cls, checkpoint_path, map_location=None, strict=True, **kwargs):
+            """Lightning's entry point as train_fit.py:349-371 / predict.py:228-256 use it: a ``.ckpt`` is a pickled dict with
+            ``state_dict`` (keys ``model.<tagger key>``) and, if the module saved them, ``hyper_parameters``; keyword arguments
+            override the latter.  HF's dead tensors in a reference checkpoint are dropped by the tagger's load hook."""
+            ckpt = torch.load(checkpoint_path, map_location=map_location or 'cpu', weights_only=False)
+            hp = dict(ckpt.get('hyper_parameters', {}) or {}) if isinstance(ckpt, dict) else {}
+            hp.update(kwargs)
+            obj = cls(**hp)
+            obj.load_state_dict(ckpt['state_dict'] if isinstance(ckpt, dict) and 'state_dict' in ckpt else ckpt, strict=strict)
+            return obj
+
 # architectures of the reference that are outside the hot path (SURVEY.md §2 rows 1b / §8f)
 _OUT_OF_SCOPE = ('SimpleBiLSTM', 'MLP', 'Transformer-CRF', 'RecurrentLongT5', 'BiLSTMRestrictedMHA', 'SwitchBiLSTM', 'SheikhBiLSTM')
 
