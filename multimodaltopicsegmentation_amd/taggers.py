@@ -55,6 +55,9 @@ def _linear_init(out_f, in_f, gen):
     return (torch.rand(out_f, in_f, generator=gen) * 2 - 1) * k, (torch.rand(out_f, generator=gen) * 2 - 1) * k
 
 
+_LENGTHS_CACHE = {}
+
+
 class _Workspace:
     """Row-capacity-based activation buffers: allocated once for the largest B*L seen, sliced per batch."""
 
@@ -129,6 +132,15 @@ class _TaggerBase(FlatModule):
     def _prep_lengths(lengths, B, L, device):
         if lengths is None:
             return torch.full((B,), L, dtype=torch.int32, device=device)
+        if lengths.device.type == 'cpu' and lengths.numel() <= 4096:
+            # a host tensor (the collater's): one small upload per distinct length vector, not one per step
+            key = (tuple(lengths.tolist()), str(device))
+            hit = _LENGTHS_CACHE.get(key)
+            if hit is None:
+                if len(_LENGTHS_CACHE) > 64:
+                    _LENGTHS_CACHE.clear()
+                hit = _LENGTHS_CACHE[key] = lengths.to(device=device, dtype=torch.int32).contiguous()
+            return hit
         return lengths.to(device=device, dtype=torch.int32).contiguous()
 
     # ---- decode (models/CRF.py:358-369) -----------------------------------------------------------
@@ -450,7 +462,10 @@ class Transformer_segmenter(_TaggerBase):
         # d(type row 0) = sum over all rows of dpre = the LayerNorm backward's column sum of dx
         ops.layernorm_bwd(st['pre0'], dh, self._w(pf, e + 'LayerNorm.weight'), st['mean0'], st['rstd0'], dpre,
                           G(e + 'LayerNorm.weight'), G(e + 'LayerNorm.bias'), dxsum=G(e + 'token_type_embeddings.weight')[0])
-        G(e + 'position_embeddings.weight').zero_()
+        # only rows [2, L+2) of the position table ever receive a gradient: keep the rest of its gradient at the zeros it was
+        # allocated with and clear what the longest batch so far could have touched
+        self._pos_touched = max(getattr(self, '_pos_touched', 0), Lq + 2)
+        G(e + 'position_embeddings.weight')[:self._pos_touched].zero_()
         ops.embed_bwd(dpre, B, Lq, G(e + 'position_embeddings.weight'), 2, row0=st['pack']['row0'] if st['pack'] else None,
                       lengths=st['lengths'])
         # embeddings: only the position rows a batch of this length can touch, then type row + LayerNorm
