@@ -161,12 +161,24 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # Warm-up with every GEMM / band-attention launch bracketed by HIP events: finds the dominant kernel symbol and fills the
+    # per-kernel table.  An event pair costs a few microseconds of stream time (14 timed launches = ~5 % of this step), so the
+    # timed region itself brackets only the launches of that dominant symbol (+ the band-attention forward, the HBM headline).
+    wtimer = None if args.no_kernel_timer else ops.KernelTimer()
+    for i in range(args.warmup):
+        ops.TIMER = wtimer if i > 0 else None        # the very first step only primes caches (which kernel the cost model picks per shape)
         trainer.step(batch)
     sync()
-    # per-launch HIP events (torch.cuda.Event on the launch stream) around the GEMM / band-attention launches of the
-    # timed region itself; recording is asynchronous and costs ~1 us of host time per event
-    timer = None if args.no_kernel_timer else ops.KernelTimer()
+    ops.TIMER = None
+    wsum = wtimer.summary() if wtimer is not None else {}
+    wsym = {}
+    for tag, (n, ms) in wsum.items():
+        if tag[0] == 'gemm':
+            wsym[(tag[1], tag[7])] = wsym.get((tag[1], tag[7]), 0.0) + ms
+    dom_key = max(wsym.items(), key=lambda kv: kv[1])[0] if wsym else None
+    # (fewer than two warm-up steps: nothing was measured yet, so bracket everything as before)
+    timer = None if args.no_kernel_timer else ops.KernelTimer(
+        only=(lambda tag: (tag[0] == 'gemm' and (tag[1], tag[7]) == dom_key) or tag[0] == 'band_fwd') if dom_key is not None else None)
     ops.TIMER = timer
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -177,7 +189,7 @@ def main():
     loss_val = float(loss)
     ksum = timer.summary() if timer is not None else {}
     if rank == 0 and os.environ.get('MTS_BENCH_DETAIL'):
-        for tag, (n, ms) in sorted(ksum.items(), key=lambda kv: -kv[1][1]):
+        for tag, (n, ms) in sorted(wsum.items(), key=lambda kv: -kv[1][1]):
             extra = ''
             if tag[0] == 'gemm':
                 extra = f' {2.0 * tag[4] * tag[5] * tag[6] * n / (ms * 1e-3) / 1e12:7.1f} TFLOP/s'
@@ -213,17 +225,21 @@ def main():
         rocprof_names = {(0, 128): ['void gemm_bf16_kernel<0, bool _Accum, bool, E>(GemmArgs)'], (1, 128): ['void gemm_bf16_kernel<1, bool _Accum, bool, E>(GemmArgs)'],
                          (2, 128): ['void gemm_bf16_kernel<2, float, true>(GemmArgs)', 'splitk_reduce_kernel(float const*, int, int, int, float*, int, int)'],
                          (0, 224): ['_Z20gemm_bf16_224_kernelILi0EDF16bEv8GemmArgs'], (1, 224): ['_Z20gemm_bf16_224_kernelILi1EDF16bEv8GemmArgs']}
-        per_sym = {}
-        other = {}
-        for tag, (n, ms) in ksum.items():
-            if tag[0] == 'gemm':
-                _, layout, a_dt, c_dt, M, N, K, tile = tag
-                d = per_sym.setdefault((layout, tile), {'launches': 0, 'ms': 0.0, 'flop': 0.0})
-                d['launches'] += n
-                d['ms'] += ms
-                d['flop'] += n * 2.0 * M * N * K
-            else:
-                other[tag[0]] = {'launches': n, 'avg_us': 1e3 * ms / n}
+        def aggregate(summary):
+            per_sym, other = {}, {}
+            for tag, (n, ms) in summary.items():
+                if tag[0] == 'gemm':
+                    _, layout, a_dt, c_dt, M, N, K, tile = tag
+                    d = per_sym.setdefault((layout, tile), {'launches': 0, 'ms': 0.0, 'flop': 0.0})
+                    d['launches'] += n
+                    d['ms'] += ms
+                    d['flop'] += n * 2.0 * M * N * K
+                else:
+                    other[tag[0]] = {'launches': n, 'avg_us': 1e3 * ms / n}
+            return per_sym, other
+
+        per_sym, other = aggregate(ksum)             # timed region: the dominant GEMM symbol and the band-attention forward only
+        wper_sym, wother = aggregate(wsum if wsum else ksum)   # warm-up steps: every GEMM / band launch
         if per_sym:
             key, dom = max(per_sym.items(), key=lambda kv: kv[1]['ms'])
             ach = dom['flop'] / (dom['ms'] * 1e-3) / 1e12
@@ -238,15 +254,16 @@ def main():
                                'unit': 'TFLOP/s', 'frac': ach / MFMA_BF16_PEAK_TFLOPS, 'traffic': traffic,
                                'launches_timed': dom['launches'], 'avg_launch_us': 1e3 * dom['ms'] / dom['launches'],
                                'algorithmic_gflop_per_launch': dom['flop'] / dom['launches'] / 1e9}
+            out['kernels_note'] = 'per-launch averages from the warm-up steps (every GEMM / band launch bracketed by HIP events); the roofline entry and band_attn_fwd are from the timed region'
             out['kernels'] = {sym.get(k, str(k)): {'launches': d['launches'], 'avg_us': 1e3 * d['ms'] / d['launches'],
-                                                    'tflops': d['flop'] / (d['ms'] * 1e-3) / 1e12} for k, d in per_sym.items()}
+                                                    'tflops': d['flop'] / (d['ms'] * 1e-3) / 1e12} for k, d in wper_sym.items()}
             # the HBM-bound headline kernel: band attention, 14 336 algorithmic bytes per sentence (bf16 q,k,v in, ctx out)
             if 'band_fwd' in other:
-                by = args.docs * args.seq * 4 * D * (2 if args.dtype == 'bf16' else 4)
+                by = int(batch['src_lengths'].sum()) * 4 * D * (2 if args.dtype == 'bf16' else 4)
                 gbs = by / (other['band_fwd']['avg_us'] * 1e-6) / 1e9
                 out['kernels']['band_attn_fwd'] = {**other['band_fwd'], 'algorithmic_GBps': gbs, 'hbm_frac': gbs / HBM_PEAK_GBS}
-            if 'band_bwd' in other:
-                out['kernels']['band_attn_bwd (2 launches)'] = other['band_bwd']
+            if 'band_bwd' in wother:
+                out['kernels']['band_attn_bwd (2 launches)'] = wother['band_bwd']
         if world == 1 and not args.no_cpu_baseline and args.arch == 'transformer':
             out['cpu_baseline'] = cpu_baseline(args, D, ff, heads, window, n_layers)
         print(json.dumps(out))

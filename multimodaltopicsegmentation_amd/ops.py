@@ -17,10 +17,15 @@ TIMER = None   # set to a KernelTimer() to time individual launches with HIP eve
 class KernelTimer:
     """Per-launch HIP-event timing (torch.cuda.Event on torch's current stream = the stream the kernels run on)."""
 
-    def __init__(self):
+    def __init__(self, only=None):
+        """only: optional predicate on the tag -- every event pair costs a few microseconds of stream time, so the timed region
+        of bench.py brackets just the launches its roofline line needs."""
         self.records = {}          # tag -> list of (start_event, end_event)
+        self.only = only
 
     def begin(self, tag):
+        if self.only is not None and not self.only(tag):
+            return None
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         self.records.setdefault(tag, []).append((s, e))
         s.record()
