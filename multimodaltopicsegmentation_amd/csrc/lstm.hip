@@ -226,10 +226,18 @@ extern "C" void mts_lstm_set_mfma(int on) { g_lstm_mfma = on; }
 static int lstm_threads(int H) { return ((H + 63) / 64) * 64; }
 
 // workspace: fwd needs W_hh^T (fp32 [ndir,H,4H]); bwd needs hprev (act dtype [B*L, ndir*H])
-extern "C" size_t mts_lstm_workspace(int dtype, int B, int L, int H, int ndir) {
-  const size_t esz = dtype == MTS_F32 ? 4 : 2;
+// first part of the workspace: scratch of whichever recurrence kernel runs (transposed / packed W_hh, the CU-pair exchange buffer);
+// once the recurrence has finished it is the split-K slab area of the dW_hh GEMMs (4H x H outputs, K = all tokens: 16 tiles at
+// H = 256 -- unsplit they would run on 16 of the 256 CUs), hence room for 16 partial planes.
+static size_t lstm_scratch_bytes(int B, int H, int ndir) {
   size_t a = std::max(align_up((size_t)ndir * 4 * H * H * sizeof(float), 256), mts_lstm_mfma_workspace(H, ndir));
   a = std::max(a, align_up(mts_lstm_pair_workspace(B, H, ndir), 256));
+  return std::max(a, align_up((size_t)16 * 4 * H * H * sizeof(float), 256));
+}
+
+extern "C" size_t mts_lstm_workspace(int dtype, int B, int L, int H, int ndir) {
+  const size_t esz = dtype == MTS_F32 ? 4 : 2;
+  const size_t a = lstm_scratch_bytes(B, H, ndir);
   const size_t b = align_up((size_t)B * L * ndir * H * esz, 256);
   return a + b;
 }
@@ -264,8 +272,7 @@ extern "C" int mts_lstm_bwd(void* stream, int dtype, int B, int L, int H, int nd
   MTS_CHECK_ARG(dtype == MTS_F32 || dtype == MTS_BF16, "mts_lstm_bwd: bad dtype %d", dtype);
   MTS_UNSUPPORTED(H <= 1024, "mts_lstm_bwd: hidden size %d > 1024", H);
   hipStream_t st = (hipStream_t)stream;
-  size_t hoff = std::max(align_up((size_t)ndir * 4 * H * H * sizeof(float), 256), mts_lstm_mfma_workspace(H, ndir));
-  hoff = std::max(hoff, align_up(mts_lstm_pair_workspace(B, H, ndir), 256));
+  const size_t hoff = lstm_scratch_bytes(B, H, ndir);
   char* hprev = (char*)workspace + hoff;
   const bool fast = g_lstm_mfma && (mts_lstm_mfma_supported(dtype, H) || mts_lstm_pair_supported(dtype, H));
   if (fast) {
@@ -298,7 +305,7 @@ extern "C" int mts_lstm_bwd(void* stream, int dtype, int B, int L, int H, int nd
   for (int d = 0; d < ndir; ++d) {
     int rc = mts_gemm(stream, dtype, MTS_F32, MTS_TN, 4 * H, H, B * L, (const char*)dxproj + (size_t)d * 4 * H * esz, ndir * 4 * H,
                       hprev + (size_t)d * H * esz, ndir * H, dw_hh + (size_t)d * 4 * H * H, H, nullptr, nullptr, 0, nullptr, 0, 0u, 1.f, 0,
-                      nullptr, 0);
+                      workspace, hoff);                  // the recurrence kernels are done with their scratch: split-K slabs
     if (rc) return rc;
   }
   return MTS_OK;
