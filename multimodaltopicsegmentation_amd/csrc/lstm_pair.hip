@@ -26,8 +26,10 @@
 
 typedef unsigned long long u64;
 
-__device__ __forceinline__ float fsig2(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float ftanh2(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
+// v_rcp_f32 (1 ulp) instead of __frcp_rn: the correctly rounded reciprocal is a ten-instruction division sequence, and the
+// 20 of them per step were a third of the time loop's instruction stream; the results are rounded to bf16 anyway
+__device__ __forceinline__ float fsig2(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float ftanh2(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 __device__ __forceinline__ uint2 pk4(const float (&v)[4]) { return make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])); }
 __device__ __forceinline__ void upk4(const uint2& u, float (&v)[4]) { v[0] = bf16_lo(u.x); v[1] = bf16_hi(u.x); v[2] = bf16_lo(u.y); v[3] = bf16_hi(u.y); }
 
@@ -63,9 +65,17 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_fwd_pair_kernel(int B, int L,
   constexpr int NT = KS * 64;                            // threads
   constexpr int GPT = 1024 / NT;                         // granules each thread fetches
   constexpr int HROW = (H + 8) * 2;
-  // xflags (MTS_LSTM_EXP, timing diagnostics only): 1 no gate/cell/out stores, 2 do not wait for the partner, 4 no posts
+  // xflags (MTS_LSTM_EXP, timing diagnostics, only in a -DMTS_LSTM_ABLATE build: the run-time switches cost scalar branches
+  // and code size in the time loop): 1 no gate/cell/out stores, 2 do not wait for the partner, 4 no posts, 8 no fetch,
+  // 16 no transcendentals, 32 no MFMA, 64 no barrier, 128 no x loads
+#ifdef MTS_LSTM_ABLATE
   const bool x_nostore = xflags & 1, x_nowait = xflags & 2, x_nopost = xflags & 4;
   const bool x_nofetch = xflags & 8, x_nomath = xflags & 16, x_nomfma = xflags & 32, x_nobar = xflags & 64, x_nox = xflags & 128;
+#else
+  constexpr bool x_nostore = false, x_nowait = false, x_nopost = false, x_nofetch = false, x_nomath = false, x_nomfma = false, x_nobar = false,
+                 x_nox = false;
+  (void)xflags;
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* hbuf = smem;                                     // [group][parity][16][HROW]
   float* blds = reinterpret_cast<float*>(smem + LP_GROUPS * 2 * LP_DOCS * HROW);   // [4][HH] this half's recurrent bias
@@ -113,7 +123,7 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_fwd_pair_kernel(int B, int L,
 
   float c[LP_GROUPS][4];
   uint2 hq[LP_GROUPS];
-  uint2 xb[LP_GROUPS][4];                                // x rows of the next step of each group (refilled right after use)
+  uint2 xb[2][LP_GROUPS][4];                             // x rows of the next TWO steps of each group, by step parity (refilled right after use)
 #pragma unroll
   for (int g = 0; g < LP_GROUPS; ++g) {
     hq[g] = make_uint2(0, 0);
@@ -127,11 +137,18 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_fwd_pair_kernel(int B, int L,
     const int t = (d == 0) ? s : (len[g] - 1 - s);
     return (long)bdoc[g] * L + t;
   };
-  auto load_x = [&](int g, int s) {
-    const long row = xrow(g, s);
+  // x rows are fetched UNCONDITIONALLY from a clamped (always valid) address: a load inside a divergent branch makes the
+  // compiler's wait-count bookkeeping give up and turn every later counted wait of the step (the poll check first of all)
+  // into "wait for everything".  Lanes past their document's end read some row of it and never use the value.
+  const bf16_t* xbase[LP_GROUPS];
 #pragma unroll
-    for (int gt = 0; gt < 4; ++gt)
-      xb[g][gt] = (row >= 0) ? *reinterpret_cast<const uint2*>(xproj + (size_t)row * ldx + (size_t)d * 4 * H + gt * H + u) : make_uint2(0, 0);
+  for (int g = 0; g < LP_GROUPS; ++g) xbase[g] = xproj + (size_t)min(bdoc[g], B - 1) * L * ldx + (size_t)d * 4 * H + u;
+  auto load_x = [&](auto parc, int g, int s) {
+    constexpr int PAR = decltype(parc)::value;
+    const int t = (d == 0) ? s : (len[g] - 1 - s);
+    const bf16_t* src = xbase[g] + (size_t)min(max(t, 0), L - 1) * ldx;
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt) xb[PAR][g][gt] = *reinterpret_cast<const uint2*>(src + gt * H);
   };
   bool dead = x_nowait;
   // partner's half of h for (group g, after step s) -> LDS hbuf[g][(s+1)&1].  The first poll is ISSUED early (before the
@@ -146,16 +163,25 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_fwd_pair_kernel(int B, int L,
   auto fetch = [&](int g, int s) {
     const u64* src = xarea(g, 1 - p, (s + 1) & 1);
     const unsigned epoch = (unsigned)(s + 1);
-    unsigned spins = 0;
-    for (;;) {
+    auto tags_ok = [&]() {
       bool ok = true;
 #pragma unroll
       for (int k = 0; k < GPT; ++k) ok &= ((unsigned)(v[k] >> 32) == epoch);
-      if (__all(ok) || dead) break;
-      if (++spins > LP_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(status, 1u); break; }
-      __builtin_amdgcn_s_sleep(1);
+      return __all(ok);
+    };
+    // the check of the poll issued earlier stands OUTSIDE the retry loop: inside it, it shares the loop header with the
+    // re-polls and the compiler can only wait for everything (x rows still in flight included) instead of a counted wait
+    if (!tags_ok() && !dead) {
+      unsigned spins = 0;
+#pragma clang loop unroll(disable)
+      for (;;) {
+        asm volatile("" : "+s"(spins));                 // opaque counter: keeps the compiler from replicating the poll hundreds of times
+        if (++spins > LP_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(status, 1u); break; }
+        __builtin_amdgcn_s_sleep(1);
 #pragma unroll
-      for (int k = 0; k < GPT; ++k) v[k] = __hip_atomic_load(src + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < GPT; ++k) v[k] = __hip_atomic_load(src + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tags_ok()) break;
+      }
     }
     char* dst = hbuf + ((g * 2 + ((s + 1) & 1)) * LP_DOCS) * HROW;
 #pragma unroll
@@ -166,8 +192,18 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_fwd_pair_kernel(int B, int L,
   };
 
 #pragma unroll
-  for (int g = 0; g < LP_GROUPS; ++g) load_x(g, 0);
+  for (int g = 0; g < LP_GROUPS; ++g) {
+    load_x(std::integral_constant<int, 0>{}, g, 0);
+    load_x(std::integral_constant<int, 1>{}, g, 1);
+  }
   __syncthreads();
+  // this lane's 4 x 4 recurrent biases stay in registers for the whole sequence
+  float bia[4][4];
+#pragma unroll
+  for (int gt = 0; gt < 4; ++gt) {
+    const float4 b4 = *reinterpret_cast<const float4*>(blds + gt * HH + ul);
+    bia[gt][0] = b4.x; bia[gt][1] = b4.y; bia[gt][2] = b4.z; bia[gt][3] = b4.w;
+  }
 
   // one time step of both groups; PAR = s & 1 is a compile-time constant so the x buffers are statically indexed
   auto step = [&](auto parc, int s) {
@@ -198,10 +234,7 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_fwd_pair_kernel(int B, int L,
       float gi[4], gf[4], gg[4], go[4];
       if (active) {
         float xi[4], xf[4], xg[4], xo[4], hn[4];
-        upk4(xb[g][0], xi); upk4(xb[g][1], xf); upk4(xb[g][2], xg); upk4(xb[g][3], xo);
-        const float4 bi = *reinterpret_cast<const float4*>(blds + ul), bf = *reinterpret_cast<const float4*>(blds + HH + ul);
-        const float4 bg = *reinterpret_cast<const float4*>(blds + 2 * HH + ul), bo = *reinterpret_cast<const float4*>(blds + 3 * HH + ul);
-        const float bia[4][4] = {{bi.x, bi.y, bi.z, bi.w}, {bf.x, bf.y, bf.z, bf.w}, {bg.x, bg.y, bg.z, bg.w}, {bo.x, bo.y, bo.z, bo.w}};
+        upk4(xb[PAR][g][0], xi); upk4(xb[PAR][g][1], xf); upk4(xb[PAR][g][2], xg); upk4(xb[PAR][g][3], xo);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (x_nomath) {
@@ -229,10 +262,15 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_fwd_pair_kernel(int B, int L,
         __hip_atomic_store(mine + doc * 64 + (ul >> 1), tag | hq[g].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(mine + doc * 64 + (ul >> 1) + 1, tag | hq[g].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      // 2) first poll of the OTHER group's partner half: posted about one phase ago, so it normally succeeds; it is
-      //    issued before the bulk stores below (vmcnt retires in order)
+      // 2) first poll of the OTHER group's partner half (posted about one phase ago when LP_GROUPS = 2)
       if (os >= 0 && !x_nofetch) fetch_issue(og, os);
-      // 3) saved state for the backward pass
+      // 3) x rows two steps ahead (same parity buffer, just consumed): loads are queued BEFORE the bulk stores -- the
+      //    vector-memory counter retires in order, so anything waited on behind a store also waits for its write ack
+      if (!x_nox) load_x(parc, g, s + 2);
+      // the OTHER group's partner half was posted one compute phase ago: finish its fetch, then both halves are in LDS
+      if (os >= 0 && !x_nofetch) fetch(og, os);
+      // 4) saved state for the backward pass, last: nothing in this step waits behind these stores, their acks arrive
+      //    under the next step's LDS reads and MFMAs
       if (active && !x_nostore) {
         bf16_t* gp = gates + (size_t)row * ldx + (size_t)d * 4 * H + u;
         *reinterpret_cast<uint2*>(gp) = pk4(gi);
@@ -242,12 +280,10 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_fwd_pair_kernel(int B, int L,
         *reinterpret_cast<float4*>(cells + (size_t)row * ldo + (size_t)d * H + u) = make_float4(c[g][0], c[g][1], c[g][2], c[g][3]);
         *reinterpret_cast<uint2*>(out + (size_t)row * ldo + (size_t)d * H + u) = hq[g];
       }
-      if (!x_nox) load_x(g, s + 1);                        // needed one step (two phases) from here
-      // the OTHER group's partner half was posted one compute phase ago: finish its fetch, then both halves are in LDS
-      if (os >= 0 && !x_nofetch) fetch(og, os);
       if (!x_nobar) __syncthreads();
     }
   };
+  __builtin_amdgcn_s_waitcnt(0);                         // clean scoreboard at the loop header (weights, biases, first x rows have landed)
   for (int s = 0; s < maxlen; s += 2) {
     step(std::integral_constant<int, 0>{}, s);
     if (s + 1 < maxlen) step(std::integral_constant<int, 1>{}, s + 1);
@@ -384,22 +420,27 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_bwd_pair_kernel(int B, int L,
   auto xarea = [&](int g, int half, int par) { return xch + ((((size_t)pair * LP_GROUPS + g) * 2 + half) * 2 + par) * 1024; };
   for (int i = tid; i < (int)((LP_GROUPS * LP_DOCS * (DAROW + HH * 4 + HH * 2)) / 4); i += NT) reinterpret_cast<unsigned*>(smem)[i] = 0u;
 
+  // saved state of (group g, step s), fetched UNCONDITIONALLY from clamped (always valid) addresses -- see load_x in the
+  // forward kernel; steps past a document's end read some row of it and the values are never used
+  size_t grow0[LP_GROUPS], orow0[LP_GROUPS];
+#pragma unroll
+  for (int g = 0; g < LP_GROUPS; ++g) {
+    const size_t b0 = (size_t)min(bdoc[g], B - 1) * L;
+    grow0[g] = b0 * ldx + (size_t)d * 4 * H + u;
+    orow0[g] = b0 * ldo + (size_t)d * H + u;
+  }
   auto load_in = [&](int g, int s, PairBwdIn& in) {
-    const bool act = (s >= 0) && (s < len[g]);
-    const int t = (d == 0) ? s : (len[g] - 1 - s);
-    const int tp = (d == 0) ? t - 1 : t + 1;
-    const size_t row = (size_t)bdoc[g] * L + (act ? t : 0);
-    const size_t prow = (size_t)bdoc[g] * L + ((act && s > 0) ? tp : 0);
-    const uint2 z2 = make_uint2(0, 0);
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bf16_t* gp = gates + row * ldx + (size_t)d * 4 * H + u;
-    in.gi = act ? *reinterpret_cast<const uint2*>(gp) : z2;
-    in.gf = act ? *reinterpret_cast<const uint2*>(gp + H) : z2;
-    in.gg = act ? *reinterpret_cast<const uint2*>(gp + 2 * H) : z2;
-    in.go = act ? *reinterpret_cast<const uint2*>(gp + 3 * H) : z2;
-    in.dov = act ? *reinterpret_cast<const uint2*>(dout + row * ldo + (size_t)d * H + u) : z2;
-    in.ct = act ? *reinterpret_cast<const float4*>(cells + row * ldo + (size_t)d * H + u) : z4;
-    in.cp = (act && s > 0) ? *reinterpret_cast<const float4*>(cells + prow * ldo + (size_t)d * H + u) : z4;
+    const int sc = max(s, 0);
+    const int t = min(max((d == 0) ? sc : (len[g] - 1 - sc), 0), L - 1);
+    const int tp = min(max((d == 0) ? t - 1 : t + 1, 0), L - 1);
+    const bf16_t* gp = gates + grow0[g] + (size_t)t * ldx;
+    in.gi = *reinterpret_cast<const uint2*>(gp);
+    in.gf = *reinterpret_cast<const uint2*>(gp + H);
+    in.gg = *reinterpret_cast<const uint2*>(gp + 2 * H);
+    in.go = *reinterpret_cast<const uint2*>(gp + 3 * H);
+    in.dov = *reinterpret_cast<const uint2*>(dout + orow0[g] + (size_t)t * ldo);
+    in.ct = *reinterpret_cast<const float4*>(cells + orow0[g] + (size_t)t * ldo);
+    in.cp = *reinterpret_cast<const float4*>(cells + orow0[g] + (size_t)tp * ldo);       // zeroed at use when s == 0
   };
   bool dead = false;
   u64 v[GPT];
@@ -412,46 +453,63 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_bwd_pair_kernel(int B, int L,
   auto fetch = [&](int g, int s) {
     const u64* src = xarea(g, 1 - p, s & 1);
     const unsigned epoch = (unsigned)(maxlen - s);
-    unsigned spins = 0;
-    for (;;) {
+    auto tags_ok = [&]() {
       bool ok = true;
 #pragma unroll
       for (int k = 0; k < GPT; ++k) ok &= ((unsigned)(v[k] >> 32) == epoch);
-      if (__all(ok) || dead) break;
-      if (++spins > LP_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(status, 2u); break; }
-      __builtin_amdgcn_s_sleep(1);
+      return __all(ok);
+    };
+    // the check of the poll issued earlier stands OUTSIDE the retry loop: inside it, it shares the loop header with the
+    // re-polls and the compiler can only wait for everything (x rows still in flight included) instead of a counted wait
+    if (!tags_ok() && !dead) {
+      unsigned spins = 0;
+#pragma clang loop unroll(disable)
+      for (;;) {
+        asm volatile("" : "+s"(spins));                 // opaque counter: keeps the compiler from replicating the poll hundreds of times
+        if (++spins > LP_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(status, 2u); break; }
+        __builtin_amdgcn_s_sleep(1);
 #pragma unroll
-      for (int k = 0; k < GPT; ++k) v[k] = __hip_atomic_load(src + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < GPT; ++k) v[k] = __hip_atomic_load(src + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tags_ok()) break;
+      }
     }
 #pragma unroll
     for (int k = 0; k < GPT; ++k) dhp[(size_t)g * LP_DOCS * (HH / 2) + tid + NT * k] = (unsigned)v[k];   // [doc][pair] = granule order
   };
 
   float dc[LP_GROUPS][4];
-  PairBwdIn in[LP_GROUPS];
+  PairBwdIn in[2][LP_GROUPS];                            // saved state of the next TWO steps, by iteration parity
 #pragma unroll
   for (int g = 0; g < LP_GROUPS; ++g) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) dc[g][r] = 0.f;
-    load_in(g, maxlen - 1, in[g]);
+    load_in(g, maxlen - 1, in[0][g]);
+    load_in(g, maxlen - 2, in[1][g]);
   }
   __syncthreads();
 
-  for (int s = maxlen - 1; s >= 0; --s) {
+  // one time step of every group; PAR = (maxlen - 1 - s) & 1 is a compile-time constant so that `in` is statically indexed.
+  // Order of the vector-memory queue within a step (its counter retires in order, so whatever is waited on also waits for
+  // everything older): [partial-dh posts] [poll] [inputs of step s-2] ... poll checked ... [dx stores] -- nothing on the
+  // step's critical path sits behind a bulk store or a streaming load.
+  auto step = [&](auto parc, int s) {
+    constexpr int PAR = decltype(parc)::value;
 #pragma unroll
     for (int g = 0; g < LP_GROUPS; ++g) {
       // ---- elementwise: dh = own partial + partner partial (+ dOut) -> gate pre-activation gradients -------------
       char* da = dabuf + g * LP_DOCS * DAROW;
       const bool active = s < len[g];
+      PairBwdIn& cur = in[PAR][g];
       float ai[4] = {0.f, 0.f, 0.f, 0.f}, af[4] = {0.f, 0.f, 0.f, 0.f}, ag[4] = {0.f, 0.f, 0.f, 0.f}, ao[4] = {0.f, 0.f, 0.f, 0.f};
       if (active) {
         const float4 own = *reinterpret_cast<const float4*>(dhl + ((size_t)g * LP_DOCS + edoc) * HH + ul);
         const uint2 oth = *reinterpret_cast<const uint2*>(dhp + ((size_t)g * LP_DOCS + edoc) * (HH / 2) + (ul >> 1));
         const float dhv[4] = {own.x + bf16_lo(oth.x), own.y + bf16_hi(oth.x), own.z + bf16_lo(oth.y), own.w + bf16_hi(oth.y)};
         float gi[4], gf[4], gg[4], go[4], dov[4];
-        upk4(in[g].gi, gi); upk4(in[g].gf, gf); upk4(in[g].gg, gg); upk4(in[g].go, go); upk4(in[g].dov, dov);
-        const float ct[4] = {in[g].ct.x, in[g].ct.y, in[g].ct.z, in[g].ct.w};
-        const float cp[4] = {in[g].cp.x, in[g].cp.y, in[g].cp.z, in[g].cp.w};
+        upk4(cur.gi, gi); upk4(cur.gf, gf); upk4(cur.gg, gg); upk4(cur.go, go); upk4(cur.dov, dov);
+        const float ct[4] = {cur.ct.x, cur.ct.y, cur.ct.z, cur.ct.w};
+        const bool has_prev = s > 0;                     // the first processed position has c_prev = 0
+        const float cp[4] = {has_prev ? cur.cp.x : 0.f, has_prev ? cur.cp.y : 0.f, has_prev ? cur.cp.z : 0.f, has_prev ? cur.cp.w : 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float tc = ftanh2(ct[r]);
@@ -470,21 +528,13 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_bwd_pair_kernel(int B, int L,
       *reinterpret_cast<uint2*>(dr + HH * 2) = qf;
       *reinterpret_cast<uint2*>(dr + 2 * HH * 2) = qg;
       *reinterpret_cast<uint2*>(dr + 3 * HH * 2) = qo;
-      // poll for the other group's partner partial (posted about a phase ago) goes out before this phase's stores
       const int og = (g + 1) % LP_GROUPS;
       const int os = (g == LP_GROUPS - 1) ? s : s + 1;   // the step of group og whose partial is needed next
       const bool need = (g == LP_GROUPS - 1) ? (s - 1 >= 0) : (s + 1 <= maxlen - 1);
-      // group og's next elementwise is (og, os - 1) for g = last, or (og, s) for g = 0; it needs the partial of step os
-      if (need) fetch_issue(og, os);
-      if (active) {
-        const int t = (d == 0) ? s : (len[g] - 1 - s);
-        bf16_t* dx = dxproj + ((size_t)bdoc[g] * L + t) * ldx + (size_t)d * 4 * H + u;
-        *reinterpret_cast<uint2*>(dx) = qi;
-        *reinterpret_cast<uint2*>(dx + H) = qf;
-        *reinterpret_cast<uint2*>(dx + 2 * H) = qg;
-        *reinterpret_cast<uint2*>(dx + 3 * H) = qo;
-      }
-      load_in(g, s - 1, in[g]);
+      // group og's next elementwise is (og, os - 1) for g = last, or (og, s) for g = 0; it needs the partial of step os.
+      // With two groups that partial was posted about a phase ago and the poll goes out here; with one group it is the
+      // partial the partner computes in THIS phase, so the poll goes out after the own posts below.
+      if (LP_GROUPS > 1 && need) fetch_issue(og, os);
       __syncthreads();
       // ---- partial dh for all 256 units from the own gate columns -------------------------------------------------
       f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
@@ -510,9 +560,24 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_bwd_pair_kernel(int B, int L,
           __hip_atomic_store(dst + 1, ((u64)tag << 32) | pk.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
+      if (LP_GROUPS == 1 && need) fetch_issue(og, os);
+      load_in(g, s - 2, in[PAR][g]);                     // same parity buffer, consumed above
       if (need) fetch(og, os);
+      if (active) {
+        const int t = (d == 0) ? s : (len[g] - 1 - s);
+        bf16_t* dx = dxproj + ((size_t)bdoc[g] * L + t) * ldx + (size_t)d * 4 * H + u;
+        *reinterpret_cast<uint2*>(dx) = qi;
+        *reinterpret_cast<uint2*>(dx + H) = qf;
+        *reinterpret_cast<uint2*>(dx + 2 * H) = qg;
+        *reinterpret_cast<uint2*>(dx + 3 * H) = qo;
+      }
       __syncthreads();
     }
+  };
+  __builtin_amdgcn_s_waitcnt(0);                         // clean scoreboard at the loop header
+  for (int s = maxlen - 1; s >= 0; s -= 2) {
+    step(std::integral_constant<int, 0>{}, s);
+    if (s - 1 >= 0) step(std::integral_constant<int, 1>{}, s - 1);
   }
   // rows >= len: zero gradients (the GEMMs that follow read every row)
 #pragma unroll
