@@ -59,7 +59,7 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_fwd_pair_kernel(int B, int L,
                                                                    const bf16_t* __restrict__ wpk, const float* __restrict__ bhh,
                                                                    const int32_t* __restrict__ lengths, bf16_t* __restrict__ out,
                                                                    bf16_t* __restrict__ gates, float* __restrict__ cells, u64* __restrict__ xch,
-                                                                   unsigned* __restrict__ status, int xflags) {
+                                                                   unsigned* __restrict__ status, char* __restrict__ dump, int xflags) {
   constexpr int H = KS * 32;
   constexpr int HH = H / 2;                              // units per workgroup
   constexpr int NT = KS * 64;                            // threads
@@ -132,17 +132,18 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_fwd_pair_kernel(int B, int L,
   }
   for (int i = tid; i < LP_GROUPS * 2 * LP_DOCS * HROW / 16; i += NT) reinterpret_cast<uint4*>(hbuf)[i] = make_uint4(0, 0, 0, 0);
 
-  auto xrow = [&](int g, int s) -> long {
-    if (s >= len[g]) return -1;
-    const int t = (d == 0) ? s : (len[g] - 1 - s);
-    return (long)bdoc[g] * L + t;
-  };
   // x rows are fetched UNCONDITIONALLY from a clamped (always valid) address: a load inside a divergent branch makes the
   // compiler's wait-count bookkeeping give up and turn every later counted wait of the step (the poll check first of all)
   // into "wait for everything".  Lanes past their document's end read some row of it and never use the value.
   const bf16_t* xbase[LP_GROUPS];
+  size_t grow0[LP_GROUPS], orow0[LP_GROUPS];             // element offsets of this lane's columns in row 0 of its document
 #pragma unroll
-  for (int g = 0; g < LP_GROUPS; ++g) xbase[g] = xproj + (size_t)min(bdoc[g], B - 1) * L * ldx + (size_t)d * 4 * H + u;
+  for (int g = 0; g < LP_GROUPS; ++g) {
+    const size_t b0 = (size_t)min(bdoc[g], B - 1) * L;
+    grow0[g] = b0 * ldx + (size_t)d * 4 * H + u;
+    orow0[g] = b0 * ldo + (size_t)d * H + u;
+    xbase[g] = xproj + grow0[g];
+  }
   auto load_x = [&](auto parc, int g, int s) {
     constexpr int PAR = decltype(parc)::value;
     const int t = (d == 0) ? s : (len[g] - 1 - s);
@@ -229,29 +230,34 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_fwd_pair_kernel(int B, int L,
 
       const int og = (g + 1) % LP_GROUPS;
       const int os = (g == LP_GROUPS - 1) ? s : s - 1;   // group og last finished step os
+      // Gate math runs on EVERY lane (documents that have ended included) and `active` only selects what is kept: no
+      // divergent branch in the step, so the compiler schedules it as one block and counts its memory waits exactly.
       const bool active = s < len[g];
-      const long row = xrow(g, s);
       float gi[4], gf[4], gg[4], go[4];
-      if (active) {
+      {
         float xi[4], xf[4], xg[4], xo[4], hn[4];
         upk4(xb[PAR][g][0], xi); upk4(xb[PAR][g][1], xf); upk4(xb[PAR][g][2], xg); upk4(xb[PAR][g][3], xo);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+          float cn;
           if (x_nomath) {
             gi[r] = (xi[r] + bia[0][r]) + acc[0][r]; gf[r] = (xf[r] + bia[1][r]) + acc[1][r];
             gg[r] = (xg[r] + bia[2][r]) + acc[2][r]; go[r] = (xo[r] + bia[3][r]) + acc[3][r];
-            c[g][r] = gf[r] * c[g][r] + gi[r] * gg[r];
-            hn[r] = go[r] * c[g][r];
+            cn = gf[r] * c[g][r] + gi[r] * gg[r];
+            hn[r] = go[r] * cn;
           } else {
             gi[r] = fsig2((xi[r] + bia[0][r]) + acc[0][r]);
             gf[r] = fsig2((xf[r] + bia[1][r]) + acc[1][r]);
             gg[r] = ftanh2((xg[r] + bia[2][r]) + acc[2][r]);
             go[r] = fsig2((xo[r] + bia[3][r]) + acc[3][r]);
-            c[g][r] = gf[r] * c[g][r] + gi[r] * gg[r];
-            hn[r] = go[r] * ftanh2(c[g][r]);
+            cn = gf[r] * c[g][r] + gi[r] * gg[r];
+            hn[r] = go[r] * ftanh2(cn);
           }
+          c[g][r] = active ? cn : c[g][r];
         }
-        hq[g] = pk4(hn);
+        const uint2 hnew = pk4(hn);
+        hq[g].x = active ? hnew.x : hq[g].x;
+        hq[g].y = active ? hnew.y : hq[g].y;
       }
       // 1) post the own half of the new h first (shortest exchange path): LDS for this workgroup, tagged granules for
       //    the partner (inactive documents carry h)
@@ -271,14 +277,18 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_fwd_pair_kernel(int B, int L,
       if (os >= 0 && !x_nofetch) fetch(og, os);
       // 4) saved state for the backward pass, last: nothing in this step waits behind these stores, their acks arrive
       //    under the next step's LDS reads and MFMAs
-      if (active && !x_nostore) {
-        bf16_t* gp = gates + (size_t)row * ldx + (size_t)d * 4 * H + u;
+      //    Lanes whose document has ended store to a dump area instead of branching around the stores.
+      if (!x_nostore) {
+        const int t = (d == 0) ? s : (len[g] - 1 - s);
+        bf16_t* gp = active ? gates + grow0[g] + (size_t)t * ldx : reinterpret_cast<bf16_t*>(dump + tid * 16);
+        float* cptr = active ? cells + orow0[g] + (size_t)t * ldo : reinterpret_cast<float*>(dump + tid * 16);
+        bf16_t* optr = active ? out + orow0[g] + (size_t)t * ldo : reinterpret_cast<bf16_t*>(dump + tid * 16);
         *reinterpret_cast<uint2*>(gp) = pk4(gi);
         *reinterpret_cast<uint2*>(gp + H) = pk4(gf);
         *reinterpret_cast<uint2*>(gp + 2 * H) = pk4(gg);
         *reinterpret_cast<uint2*>(gp + 3 * H) = pk4(go);
-        *reinterpret_cast<float4*>(cells + (size_t)row * ldo + (size_t)d * H + u) = make_float4(c[g][0], c[g][1], c[g][2], c[g][3]);
-        *reinterpret_cast<uint2*>(out + (size_t)row * ldo + (size_t)d * H + u) = hq[g];
+        *reinterpret_cast<float4*>(cptr) = make_float4(c[g][0], c[g][1], c[g][2], c[g][3]);
+        *reinterpret_cast<uint2*>(optr) = hq[g];
       }
       if (!x_nobar) __syncthreads();
     }
@@ -307,7 +317,9 @@ bool mts_lstm_pair_supported(int dtype, int H) {
 // workspace: packed weights (bf16) | exchange granules | status word
 static size_t pair_wbytes(int H, int ndir) { return align_up((size_t)ndir * 4 * H * H * 2, 256); }
 static size_t pair_xbytes(int B, int ndir) { return align_up((size_t)ceil_div(B, LP_DOCS * LP_GROUPS) * ndir * LP_GROUPS * 2 * 2 * 1024 * sizeof(u64), 256); }
-size_t mts_lstm_pair_workspace(int B, int H, int ndir) { return pair_wbytes(H, ndir) + pair_xbytes(B, ndir) + 256; }
+// ... | status word (256 B) | dump area (stores of lanes whose document has ended)
+#define LP_DUMP_BYTES 16384
+size_t mts_lstm_pair_workspace(int B, int H, int ndir) { return pair_wbytes(H, ndir) + pair_xbytes(B, ndir) + 256 + LP_DUMP_BYTES; }
 
 int mts_lstm_pair_fwd(hipStream_t st, int B, int L, int H, int ndir, const void* xproj, const float* w_hh, const float* b_hh,
                       const int32_t* lengths, void* out, void* gates, float* cells, void* ws) {
@@ -332,7 +344,7 @@ int mts_lstm_pair_fwd(hipStream_t st, int B, int L, int H, int ndir, const void*
   if (xflags < 0) { const char* e = getenv("MTS_LSTM_EXP"); xflags = e ? atoi(e) : 0; }
   const int npairs = ceil_div(B, LP_DOCS * LP_GROUPS) * ndir;
   hipLaunchKernelGGL(k, dim3(16 * ceil_div(npairs, 8)), dim3(KS * 64), lds, st, B, L, ndir, npairs, (const bf16_t*)xproj, (const bf16_t*)wpk, b_hh,
-                     lengths, (bf16_t*)out, (bf16_t*)gates, cells, xch, status, xflags);
+                     lengths, (bf16_t*)out, (bf16_t*)gates, cells, xch, status, (char*)status + 256, xflags);
   MTS_LAUNCH_CHECK("mts_lstm_fwd(pair)");
   return MTS_OK;
 }
@@ -373,7 +385,8 @@ template <int KS>
 __global__ __launch_bounds__(KS * 64, 2) void lstm_bwd_pair_kernel(int B, int L, int ndir, int npairs, const bf16_t* __restrict__ wpkT,
                                                                    const int32_t* __restrict__ lengths, const bf16_t* __restrict__ gates,
                                                                    const float* __restrict__ cells, const bf16_t* __restrict__ dout,
-                                                                   bf16_t* __restrict__ dxproj, u64* __restrict__ xch, unsigned* __restrict__ status) {
+                                                                   bf16_t* __restrict__ dxproj, u64* __restrict__ xch, unsigned* __restrict__ status,
+                                                                   char* __restrict__ dump) {
   constexpr int H = KS * 32, HH = H / 2, NT = KS * 64, GPT = 1024 / NT;
   constexpr int KT = 4 * HH / 32;                        // k-steps over the 512 own gate columns
   constexpr int RK = KT + KT / 2;                        // fragments kept in registers: tile 0 all, tile 1 first half
@@ -500,8 +513,9 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_bwd_pair_kernel(int B, int L,
       char* da = dabuf + g * LP_DOCS * DAROW;
       const bool active = s < len[g];
       PairBwdIn& cur = in[PAR][g];
-      float ai[4] = {0.f, 0.f, 0.f, 0.f}, af[4] = {0.f, 0.f, 0.f, 0.f}, ag[4] = {0.f, 0.f, 0.f, 0.f}, ao[4] = {0.f, 0.f, 0.f, 0.f};
-      if (active) {
+      // elementwise math on every lane, `active` selects (see the forward kernel)
+      float ai[4], af[4], ag[4], ao[4];
+      {
         const float4 own = *reinterpret_cast<const float4*>(dhl + ((size_t)g * LP_DOCS + edoc) * HH + ul);
         const uint2 oth = *reinterpret_cast<const uint2*>(dhp + ((size_t)g * LP_DOCS + edoc) * (HH / 2) + (ul >> 1));
         const float dhv[4] = {own.x + bf16_lo(oth.x), own.y + bf16_hi(oth.x), own.z + bf16_lo(oth.y), own.w + bf16_hi(oth.y)};
@@ -515,11 +529,11 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_bwd_pair_kernel(int B, int L,
           const float tc = ftanh2(ct[r]);
           const float dht = dov[r] + dhv[r];
           const float dct = dc[g][r] + dht * go[r] * (1.f - tc * tc);
-          ai[r] = dct * gg[r] * gi[r] * (1.f - gi[r]);
-          af[r] = dct * cp[r] * gf[r] * (1.f - gf[r]);
-          ag[r] = dct * gi[r] * (1.f - gg[r] * gg[r]);
-          ao[r] = dht * tc * go[r] * (1.f - go[r]);
-          dc[g][r] = dct * gf[r];
+          ai[r] = active ? dct * gg[r] * gi[r] * (1.f - gi[r]) : 0.f;
+          af[r] = active ? dct * cp[r] * gf[r] * (1.f - gf[r]) : 0.f;
+          ag[r] = active ? dct * gi[r] * (1.f - gg[r] * gg[r]) : 0.f;
+          ao[r] = active ? dht * tc * go[r] * (1.f - go[r]) : 0.f;
+          dc[g][r] = active ? dct * gf[r] : dc[g][r];
         }
       }
       const uint2 qi = pk4(ai), qf = pk4(af), qg = pk4(ag), qo = pk4(ao);
@@ -563,9 +577,9 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_bwd_pair_kernel(int B, int L,
       if (LP_GROUPS == 1 && need) fetch_issue(og, os);
       load_in(g, s - 2, in[PAR][g]);                     // same parity buffer, consumed above
       if (need) fetch(og, os);
-      if (active) {
+      {
         const int t = (d == 0) ? s : (len[g] - 1 - s);
-        bf16_t* dx = dxproj + ((size_t)bdoc[g] * L + t) * ldx + (size_t)d * 4 * H + u;
+        bf16_t* dx = active ? dxproj + grow0[g] + (size_t)t * ldx : reinterpret_cast<bf16_t*>(dump + tid * 16);
         *reinterpret_cast<uint2*>(dx) = qi;
         *reinterpret_cast<uint2*>(dx + H) = qf;
         *reinterpret_cast<uint2*>(dx + 2 * H) = qg;
@@ -629,7 +643,7 @@ int mts_lstm_pair_bwd(hipStream_t st, int B, int L, int H, int ndir, const float
   }
   const int npairs = ceil_div(B, LP_DOCS * LP_GROUPS) * ndir;
   hipLaunchKernelGGL(k, dim3(16 * ceil_div(npairs, 8)), dim3(KS * 64), lds, st, B, L, ndir, npairs, (const bf16_t*)wpk, lengths, (const bf16_t*)gates,
-                     cells, (const bf16_t*)dout, (bf16_t*)dxproj, xch, status);
+                     cells, (const bf16_t*)dout, (bf16_t*)dxproj, xch, status, (char*)status + 256);
   MTS_LAUNCH_CHECK("mts_lstm_bwd(pair)");
   return MTS_OK;
 }
