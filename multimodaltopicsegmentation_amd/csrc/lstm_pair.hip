@@ -118,7 +118,7 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_fwd_pair_kernel(int B, int L,
 #pragma unroll
   for (int off = 1; off < 16; off <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
 
-  // exchange areas: xch[pair][group][half][parity][1024 granules]; granule index = doc*64 + (unit within half)/2
+  // exchange areas: xch[pair][group][half][parity][1024 granules]
   auto xarea = [&](int g, int half, int par) { return xch + ((((size_t)pair * LP_GROUPS + g) * 2 + half) * 2 + par) * 1024; };
 
   float c[LP_GROUPS][4];
@@ -187,8 +187,9 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_fwd_pair_kernel(int B, int L,
     char* dst = hbuf + ((g * 2 + ((s + 1) & 1)) * LP_DOCS) * HROW;
 #pragma unroll
     for (int k = 0; k < GPT; ++k) {
-      const int gi = tid + NT * k;                       // granule: doc = gi / 64, unit pair = gi % 64
-      *reinterpret_cast<unsigned*>(dst + (gi >> 6) * HROW + ((1 - p) * HH + (gi & 63) * 2) * 2) = (unsigned)v[k];
+      const int gi = tid + NT * k;                       // granule: half-quad k2 = gi / 512, quad = (gi % 512) / 16, doc = gi % 16
+      const int k2 = gi >> 9, quad = (gi & 511) >> 4, dd = gi & 15;
+      *reinterpret_cast<unsigned*>(dst + dd * HROW + ((1 - p) * HH + quad * 4 + k2 * 2) * 2) = (unsigned)v[k];
     }
   };
 
@@ -265,8 +266,10 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_fwd_pair_kernel(int B, int L,
       if (!x_nopost) {
         u64* mine = xarea(g, p, PAR ^ 1);
         const u64 tag = (u64)(unsigned)(s + 1) << 32;
-        __hip_atomic_store(mine + doc * 64 + (ul >> 1), tag | hq[g].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(mine + doc * 64 + (ul >> 1) + 1, tag | hq[g].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // granule k of (document, unit quad) sits at k * 512 + quad * 16 + document: each of the two stores of a wave is one
+        // contiguous 512-byte access (quad = ul / 4 = 4 * wave + lane / 16), and so is each poll of the partner
+        __hip_atomic_store(mine + (ul >> 2) * 16 + doc, tag | hq[g].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 512 + (ul >> 2) * 16 + doc, tag | hq[g].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       // 2) first poll of the OTHER group's partner half (posted about one phase ago when LP_GROUPS = 2)
       if (os >= 0 && !x_nofetch) fetch_issue(og, os);
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_bwd_pair_kernel(int B, int L,
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* dabuf = smem;                                                       // [group][16][DAROW] bf16
   float* dhl = reinterpret_cast<float*>(dabuf + LP_GROUPS * LP_DOCS * DAROW);   // [group][16][HH] own partial (fp32)
-  unsigned* dhp = reinterpret_cast<unsigned*>(dhl + LP_GROUPS * LP_DOCS * HH);   // [group][16][HH/2] partner partial (2 x bf16)
+  unsigned* dhp = reinterpret_cast<unsigned*>(dhl + LP_GROUPS * LP_DOCS * HH);   // (formerly the staged partner partial; kept so that the layout below is unchanged)
   char* wlds = reinterpret_cast<char*>(dhp + LP_GROUPS * LP_DOCS * HH / 2);     // [wave][KT/2][1024]
   const int chunk = blockIdx.x / 16, within = blockIdx.x % 16;
   const int p = within / 8, pair = chunk * 8 + within % 8;
@@ -458,13 +461,18 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_bwd_pair_kernel(int B, int L,
   bool dead = false;
   u64 v[GPT];
   // partner's partial dh for my units, produced in its MFMA of (group g, step s); tag = maxlen - s (>= 1)
+  // Every thread polls exactly the two granules of its own (document, unit quad): the values stay in registers, there is
+  // no LDS staging of the partner's partial and the wait for it overlaps the workgroup barrier.  Granule k of (document,
+  // quad) sits at k * 512 + quad * 16 + document = k * 512 + (the polling thread's id): polls and posts are both
+  // contiguous 512-byte wave accesses.
+  static_assert(LP_GROUPS == 1 && GPT == 2, "backward pair kernel: one group per pair, one unit quad (two granules) per thread");
   auto fetch_issue = [&](int g, int s) {
-    const u64* src = xarea(g, 1 - p, s & 1);
+    const u64* src = xarea(g, 1 - p, s & 1) + tid;
 #pragma unroll
-    for (int k = 0; k < GPT; ++k) v[k] = __hip_atomic_load(src + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int k = 0; k < GPT; ++k) v[k] = __hip_atomic_load(src + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   auto fetch = [&](int g, int s) {
-    const u64* src = xarea(g, 1 - p, s & 1);
+    const u64* src = xarea(g, 1 - p, s & 1) + tid;
     const unsigned epoch = (unsigned)(maxlen - s);
     auto tags_ok = [&]() {
       bool ok = true;
@@ -482,12 +490,10 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_bwd_pair_kernel(int B, int L,
         if (++spins > LP_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(status, 2u); break; }
         __builtin_amdgcn_s_sleep(1);
 #pragma unroll
-        for (int k = 0; k < GPT; ++k) v[k] = __hip_atomic_load(src + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < GPT; ++k) v[k] = __hip_atomic_load(src + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tags_ok()) break;
       }
     }
-#pragma unroll
-    for (int k = 0; k < GPT; ++k) dhp[(size_t)g * LP_DOCS * (HH / 2) + tid + NT * k] = (unsigned)v[k];   // [doc][pair] = granule order
   };
 
   float dc[LP_GROUPS][4];
@@ -503,8 +509,8 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_bwd_pair_kernel(int B, int L,
 
   // one time step of every group; PAR = (maxlen - 1 - s) & 1 is a compile-time constant so that `in` is statically indexed.
   // Order of the vector-memory queue within a step (its counter retires in order, so whatever is waited on also waits for
-  // everything older): [partial-dh posts] [poll] [inputs of step s-2] ... poll checked ... [dx stores] -- nothing on the
-  // step's critical path sits behind a bulk store or a streaming load.
+  // everything older): [partial-dh posts] [poll] [inputs of step s-2] [dx stores] barrier ... poll checked at the start of
+  // the next step.
   auto step = [&](auto parc, int s) {
     constexpr int PAR = decltype(parc)::value;
 #pragma unroll
@@ -517,7 +523,11 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_bwd_pair_kernel(int B, int L,
       float ai[4], af[4], ag[4], ao[4];
       {
         const float4 own = *reinterpret_cast<const float4*>(dhl + ((size_t)g * LP_DOCS + edoc) * HH + ul);
-        const uint2 oth = *reinterpret_cast<const uint2*>(dhp + ((size_t)g * LP_DOCS + edoc) * (HH / 2) + (ul >> 1));
+        uint2 oth = make_uint2(0, 0);                    // partner's partial from its MFMA of step s + 1 (polled at the end of that step)
+        if (s + 1 <= maxlen - 1) {
+          fetch(g, s + 1);
+          oth = make_uint2((unsigned)v[0], (unsigned)v[1]);
+        }
         const float dhv[4] = {own.x + bf16_lo(oth.x), own.y + bf16_hi(oth.x), own.z + bf16_lo(oth.y), own.w + bf16_hi(oth.y)};
         float gi[4], gf[4], gg[4], go[4], dov[4];
         upk4(cur.gi, gi); upk4(cur.gf, gf); upk4(cur.gg, gg); upk4(cur.go, go); upk4(cur.dov, dov);
@@ -542,13 +552,6 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_bwd_pair_kernel(int B, int L,
       *reinterpret_cast<uint2*>(dr + HH * 2) = qf;
       *reinterpret_cast<uint2*>(dr + 2 * HH * 2) = qg;
       *reinterpret_cast<uint2*>(dr + 3 * HH * 2) = qo;
-      const int og = (g + 1) % LP_GROUPS;
-      const int os = (g == LP_GROUPS - 1) ? s : s + 1;   // the step of group og whose partial is needed next
-      const bool need = (g == LP_GROUPS - 1) ? (s - 1 >= 0) : (s + 1 <= maxlen - 1);
-      // group og's next elementwise is (og, os - 1) for g = last, or (og, s) for g = 0; it needs the partial of step os.
-      // With two groups that partial was posted about a phase ago and the poll goes out here; with one group it is the
-      // partial the partner computes in THIS phase, so the poll goes out after the own posts below.
-      if (LP_GROUPS > 1 && need) fetch_issue(og, os);
       __syncthreads();
       // ---- partial dh for all 256 units from the own gate columns -------------------------------------------------
       f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
@@ -567,16 +570,15 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_bwd_pair_kernel(int B, int L,
         if (mine_half) {
           *reinterpret_cast<float4*>(dhl + ((size_t)g * LP_DOCS + mdoc) * HH + ulw) = make_float4(acc[t2][0], acc[t2][1], acc[t2][2], acc[t2][3]);
         } else {
-          u64* dst = xarea(g, p, s & 1) + mdoc * 64 + (ulw >> 1);
+          u64* dst = xarea(g, p, s & 1) + (ulw >> 2) * 16 + mdoc;
           const float vv[4] = {acc[t2][0], acc[t2][1], acc[t2][2], acc[t2][3]};
           const uint2 pk = pk4(vv);
           __hip_atomic_store(dst, ((u64)tag << 32) | pk.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(dst + 1, ((u64)tag << 32) | pk.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(dst + NT, ((u64)tag << 32) | pk.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
-      if (LP_GROUPS == 1 && need) fetch_issue(og, os);
+      if (s - 1 >= 0) fetch_issue(g, s);                 // the partner computes its partial for my units in this same phase
       load_in(g, s - 2, in[PAR][g]);                     // same parity buffer, consumed above
-      if (need) fetch(og, os);
       {
         const int t = (d == 0) ? s : (len[g] - 1 - s);
         bf16_t* dx = active ? dxproj + grow0[g] + (size_t)t * ldx : reinterpret_cast<bf16_t*>(dump + tid * 16);
