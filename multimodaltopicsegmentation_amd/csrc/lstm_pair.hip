@@ -358,8 +358,9 @@ int mts_lstm_pair_fwd(hipStream_t st, int B, int L, int H, int ndir, const void*
 // keeps the 128 columns of its own units (LDS, fp32) and sends the other 128 to the partner as bf16 granules.
 // Elementwise gate-gradient work is spread over all 512 threads (thread = document x 4 own units).
 // =====================================================================================================
-// packed: wpkT[d][p][w][t][ks][lane] = 8 bf16: A fragment row = unit j = w*32 + t*16 + (lane&15), k = own column index
-// kk = ks*32 + 8*(lane>>4) .. +7, i.e. W_hh[gate*H + p*H/2 + kk%128][j] with gate = kk/128
+// packed: wpkT[d][p][w][t][ks][lane] = 8 bf16: A fragment row = output unit j, tile t = 0: unit w*16 + (lane&15) of THIS half,
+// t = 1: the same unit of the PARTNER's half; k = own column index kk = ks*32 + 8*(lane>>4) .. +7, i.e.
+// W_hh[gate*H + p*H/2 + kk%128][j] with gate = kk/128
 __global__ void lstm_pack_weights_T_kernel(const float* __restrict__ w_hh, bf16_t* __restrict__ wpk, int H, int ndir) {
   const int HH = H / 2, KT = 4 * HH / 32, NW = H / 32;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // over d, p, w, t, ks, lane
@@ -372,7 +373,7 @@ __global__ void lstm_pack_weights_T_kernel(const float* __restrict__ w_hh, bf16_
   const int w = r % NW; r /= NW;
   const int p = r % 2; r /= 2;
   const int d = (int)r;
-  const int j = w * 32 + t * 16 + (lane & 15);
+  const int j = (t == 0 ? p : 1 - p) * HH + w * 16 + (lane & 15);
   bf16_t* dst = wpk + idx * 8;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -384,30 +385,35 @@ __global__ void lstm_pack_weights_T_kernel(const float* __restrict__ w_hh, bf16_
 
 struct PairBwdIn { uint2 gi, gf, gg, go, dov; float4 ct, cp; };
 
+// Step structure (the forward kernel's, mirrored: one workgroup barrier and one LDS round trip per time step).  Wave w
+// owns output tile 0 = units w*16..+15 of THIS half and tile 1 = the same units of the PARTNER's half; both are reduced over
+// this half's 512 gate columns.  The MFMA result layout (lane = document x 4 units) IS the elementwise layout: a lane
+// keeps its own partial of dh in registers, posts the partner-tile partial, polls the partner's partial for exactly its
+// (document, unit quad) into registers, does the gate-gradient math and writes da to LDS (double-buffered by step parity);
+// after the barrier every wave reads da and runs its MFMAs for the previous time step.
 template <int KS>
 __global__ __launch_bounds__(KS * 64, 2) void lstm_bwd_pair_kernel(int B, int L, int ndir, int npairs, const bf16_t* __restrict__ wpkT,
                                                                    const int32_t* __restrict__ lengths, const bf16_t* __restrict__ gates,
                                                                    const float* __restrict__ cells, const bf16_t* __restrict__ dout,
                                                                    bf16_t* __restrict__ dxproj, u64* __restrict__ xch, unsigned* __restrict__ status,
                                                                    char* __restrict__ dump) {
-  constexpr int H = KS * 32, HH = H / 2, NT = KS * 64, GPT = 1024 / NT;
+  static_assert(LP_GROUPS == 1 && KS == 8, "the backward pair kernel serves one group of documents per pair, H = 256");
+  constexpr int H = KS * 32, HH = H / 2, NT = KS * 64;
   constexpr int KT = 4 * HH / 32;                        // k-steps over the 512 own gate columns
   constexpr int RK = KT + KT / 2;                        // fragments kept in registers: tile 0 all, tile 1 first half
   constexpr int DAROW = (4 * HH + 8) * 2;                // bytes per da row
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* dabuf = smem;                                                       // [group][16][DAROW] bf16
-  float* dhl = reinterpret_cast<float*>(dabuf + LP_GROUPS * LP_DOCS * DAROW);   // [group][16][HH] own partial (fp32)
-  unsigned* dhp = reinterpret_cast<unsigned*>(dhl + LP_GROUPS * LP_DOCS * HH);   // (formerly the staged partner partial; kept so that the layout below is unchanged)
-  char* wlds = reinterpret_cast<char*>(dhp + LP_GROUPS * LP_DOCS * HH / 2);     // [wave][KT/2][1024]
+  char* dabuf = smem;                                    // [2 (step parity)][16][DAROW] bf16
+  char* wlds = dabuf + 2 * LP_DOCS * DAROW;              // [wave][KT/2][1024]
   const int chunk = blockIdx.x / 16, within = blockIdx.x % 16;
   const int p = within / 8, pair = chunk * 8 + within % 8;
   if (pair >= npairs) return;
   const int gx = pair / ndir, d = pair % ndir;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int mdoc = lane & 15, g4 = lane >> 4;            // MFMA lane roles
-  const int edoc = tid & 15, eq = tid >> 4;              // elementwise roles: document, unit quad (4 own units)
-  const int ul = eq * 4, u = p * HH + ul;
+  const int doc = lane & 15, g4 = lane >> 4;
+  const int ul = w * 16 + 4 * g4;                        // this lane's 4 units, within the half
+  const int u = p * HH + ul;                             // ... within H
   const int ldx = ndir * 4 * H, ldo = ndir * H;
 
   bf16x8 wreg[RK];
@@ -421,67 +427,48 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_bwd_pair_kernel(int B, int L,
       *reinterpret_cast<bf16x8*>(wl + f * 1024 + lane * 16) = *reinterpret_cast<const bf16x8*>(base + ((size_t)(RK + f) * 64 + lane) * 8);
   }
 
-  int bdoc[LP_GROUPS], len[LP_GROUPS];
-  int maxlen = 0;
-#pragma unroll
-  for (int g = 0; g < LP_GROUPS; ++g) {
-    bdoc[g] = (gx * LP_GROUPS + g) * LP_DOCS + edoc;
-    len[g] = (bdoc[g] < B) ? (lengths ? min(lengths[bdoc[g]], L) : L) : 0;
-    maxlen = max(maxlen, len[g]);
-  }
+  const int bdoc = gx * LP_DOCS + doc;
+  const int len = (bdoc < B) ? (lengths ? min(lengths[bdoc], L) : L) : 0;
+  int maxlen = len;
 #pragma unroll
   for (int off = 1; off < 16; off <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
-  // (tid & 15 == lane & 15, so the xor-reduction over 16 lanes covers the 16 documents for both lane roles)
 
-  auto xarea = [&](int g, int half, int par) { return xch + ((((size_t)pair * LP_GROUPS + g) * 2 + half) * 2 + par) * 1024; };
-  for (int i = tid; i < (int)((LP_GROUPS * LP_DOCS * (DAROW + HH * 4 + HH * 2)) / 4); i += NT) reinterpret_cast<unsigned*>(smem)[i] = 0u;
+  // exchange areas: xch[pair][half][parity][1024 granules]; granule k of (document, unit quad) sits at k * 512 + quad * 16 +
+  // document = k * 512 + tid for the lane that owns the position on EITHER side: posts and polls are contiguous 512-byte
+  // wave accesses and a poll lands in the consuming lane's registers
+  auto xarea = [&](int half, int par) { return xch + (((size_t)pair * 2 + half) * 2 + par) * 1024; };
+  for (int i = tid; i < 2 * LP_DOCS * DAROW / 4; i += NT) reinterpret_cast<unsigned*>(smem)[i] = 0u;
 
-  // saved state of (group g, step s), fetched UNCONDITIONALLY from clamped (always valid) addresses -- see load_x in the
-  // forward kernel; steps past a document's end read some row of it and the values are never used
-  size_t grow0[LP_GROUPS], orow0[LP_GROUPS];
-#pragma unroll
-  for (int g = 0; g < LP_GROUPS; ++g) {
-    const size_t b0 = (size_t)min(bdoc[g], B - 1) * L;
-    grow0[g] = b0 * ldx + (size_t)d * 4 * H + u;
-    orow0[g] = b0 * ldo + (size_t)d * H + u;
-  }
-  auto load_in = [&](int g, int s, PairBwdIn& in) {
+  // saved state of step s, fetched UNCONDITIONALLY from clamped (always valid) addresses -- see load_x in the forward
+  // kernel; steps past a document's end read some row of it and the values are never used
+  const size_t b0 = (size_t)min(bdoc, B - 1) * L;
+  const size_t grow0 = b0 * ldx + (size_t)d * 4 * H + u;
+  const size_t orow0 = b0 * ldo + (size_t)d * H + u;
+  auto load_in = [&](int s, PairBwdIn& in) {
     const int sc = max(s, 0);
-    const int t = min(max((d == 0) ? sc : (len[g] - 1 - sc), 0), L - 1);
+    const int t = min(max((d == 0) ? sc : (len - 1 - sc), 0), L - 1);
     const int tp = min(max((d == 0) ? t - 1 : t + 1, 0), L - 1);
-    const bf16_t* gp = gates + grow0[g] + (size_t)t * ldx;
+    const bf16_t* gp = gates + grow0 + (size_t)t * ldx;
     in.gi = *reinterpret_cast<const uint2*>(gp);
     in.gf = *reinterpret_cast<const uint2*>(gp + H);
     in.gg = *reinterpret_cast<const uint2*>(gp + 2 * H);
     in.go = *reinterpret_cast<const uint2*>(gp + 3 * H);
-    in.dov = *reinterpret_cast<const uint2*>(dout + orow0[g] + (size_t)t * ldo);
-    in.ct = *reinterpret_cast<const float4*>(cells + orow0[g] + (size_t)t * ldo);
-    in.cp = *reinterpret_cast<const float4*>(cells + orow0[g] + (size_t)tp * ldo);       // zeroed at use when s == 0
+    in.dov = *reinterpret_cast<const uint2*>(dout + orow0 + (size_t)t * ldo);
+    in.ct = *reinterpret_cast<const float4*>(cells + orow0 + (size_t)t * ldo);
+    in.cp = *reinterpret_cast<const float4*>(cells + orow0 + (size_t)tp * ldo);       // zeroed at use when s == 0
   };
   bool dead = false;
-  u64 v[GPT];
-  // partner's partial dh for my units, produced in its MFMA of (group g, step s); tag = maxlen - s (>= 1)
-  // Every thread polls exactly the two granules of its own (document, unit quad): the values stay in registers, there is
-  // no LDS staging of the partner's partial and the wait for it overlaps the workgroup barrier.  Granule k of (document,
-  // quad) sits at k * 512 + quad * 16 + document = k * 512 + (the polling thread's id): polls and posts are both
-  // contiguous 512-byte wave accesses.
-  static_assert(LP_GROUPS == 1 && GPT == 2, "backward pair kernel: one group per pair, one unit quad (two granules) per thread");
-  auto fetch_issue = [&](int g, int s) {
-    const u64* src = xarea(g, 1 - p, s & 1) + tid;
-#pragma unroll
-    for (int k = 0; k < GPT; ++k) v[k] = __hip_atomic_load(src + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  u64 v[2];
+  // partner's partial dh for my quad, produced in its MFMA of step s; tag = maxlen - s (>= 1)
+  auto fetch_issue = [&](int s) {
+    const u64* src = xarea(1 - p, s & 1) + tid;
+    v[0] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v[1] = __hip_atomic_load(src + NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  auto fetch = [&](int g, int s) {
-    const u64* src = xarea(g, 1 - p, s & 1) + tid;
+  auto fetch = [&](int s) {
     const unsigned epoch = (unsigned)(maxlen - s);
-    auto tags_ok = [&]() {
-      bool ok = true;
-#pragma unroll
-      for (int k = 0; k < GPT; ++k) ok &= ((unsigned)(v[k] >> 32) == epoch);
-      return __all(ok);
-    };
-    // the check of the poll issued earlier stands OUTSIDE the retry loop: inside it, it shares the loop header with the
-    // re-polls and the compiler can only wait for everything (x rows still in flight included) instead of a counted wait
+    auto tags_ok = [&]() { return __all(((unsigned)(v[0] >> 32) == epoch) & ((unsigned)(v[1] >> 32) == epoch)); };
+    // the check of the poll issued earlier stands OUTSIDE the retry loop (counted wait, see the forward kernel)
     if (!tags_ok() && !dead) {
       unsigned spins = 0;
 #pragma clang loop unroll(disable)
@@ -489,106 +476,84 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_bwd_pair_kernel(int B, int L,
         asm volatile("" : "+s"(spins));                 // opaque counter: keeps the compiler from replicating the poll hundreds of times
         if (++spins > LP_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(status, 2u); break; }
         __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-        for (int k = 0; k < GPT; ++k) v[k] = __hip_atomic_load(src + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fetch_issue(s);
         if (tags_ok()) break;
       }
     }
   };
 
-  float dc[LP_GROUPS][4];
-  PairBwdIn in[2][LP_GROUPS];                            // saved state of the next TWO steps, by iteration parity
-#pragma unroll
-  for (int g = 0; g < LP_GROUPS; ++g) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) dc[g][r] = 0.f;
-    load_in(g, maxlen - 1, in[0][g]);
-    load_in(g, maxlen - 2, in[1][g]);
-  }
+  float dc[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x4 own = (f32x4){0.f, 0.f, 0.f, 0.f};               // own partial of dh for this lane's quad, from the previous MFMA phase
+  PairBwdIn in[2];                                       // saved state of the next TWO steps, by iteration parity
+  load_in(maxlen - 1, in[0]);
+  load_in(maxlen - 2, in[1]);
   __syncthreads();
 
-  // one time step of every group; PAR = (maxlen - 1 - s) & 1 is a compile-time constant so that `in` is statically indexed.
-  // Order of the vector-memory queue within a step (its counter retires in order, so whatever is waited on also waits for
-  // everything older): [partial-dh posts] [poll] [inputs of step s-2] [dx stores] barrier ... poll checked at the start of
-  // the next step.
+  // one time step; PAR = (maxlen - 1 - s) & 1 is a compile-time constant so that `in` and the da buffer are statically indexed
   auto step = [&](auto parc, int s) {
     constexpr int PAR = decltype(parc)::value;
-#pragma unroll
-    for (int g = 0; g < LP_GROUPS; ++g) {
-      // ---- elementwise: dh = own partial + partner partial (+ dOut) -> gate pre-activation gradients -------------
-      char* da = dabuf + g * LP_DOCS * DAROW;
-      const bool active = s < len[g];
-      PairBwdIn& cur = in[PAR][g];
-      // elementwise math on every lane, `active` selects (see the forward kernel)
-      float ai[4], af[4], ag[4], ao[4];
-      {
-        const float4 own = *reinterpret_cast<const float4*>(dhl + ((size_t)g * LP_DOCS + edoc) * HH + ul);
-        uint2 oth = make_uint2(0, 0);                    // partner's partial from its MFMA of step s + 1 (polled at the end of that step)
-        if (s + 1 <= maxlen - 1) {
-          fetch(g, s + 1);
-          oth = make_uint2((unsigned)v[0], (unsigned)v[1]);
-        }
-        const float dhv[4] = {own.x + bf16_lo(oth.x), own.y + bf16_hi(oth.x), own.z + bf16_lo(oth.y), own.w + bf16_hi(oth.y)};
-        float gi[4], gf[4], gg[4], go[4], dov[4];
-        upk4(cur.gi, gi); upk4(cur.gf, gf); upk4(cur.gg, gg); upk4(cur.go, go); upk4(cur.dov, dov);
-        const float ct[4] = {cur.ct.x, cur.ct.y, cur.ct.z, cur.ct.w};
-        const bool has_prev = s > 0;                     // the first processed position has c_prev = 0
-        const float cp[4] = {has_prev ? cur.cp.x : 0.f, has_prev ? cur.cp.y : 0.f, has_prev ? cur.cp.z : 0.f, has_prev ? cur.cp.w : 0.f};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float tc = ftanh2(ct[r]);
-          const float dht = dov[r] + dhv[r];
-          const float dct = dc[g][r] + dht * go[r] * (1.f - tc * tc);
-          ai[r] = active ? dct * gg[r] * gi[r] * (1.f - gi[r]) : 0.f;
-          af[r] = active ? dct * cp[r] * gf[r] * (1.f - gf[r]) : 0.f;
-          ag[r] = active ? dct * gi[r] * (1.f - gg[r] * gg[r]) : 0.f;
-          ao[r] = active ? dht * tc * go[r] * (1.f - go[r]) : 0.f;
-          dc[g][r] = active ? dct * gf[r] : dc[g][r];
-        }
-      }
-      const uint2 qi = pk4(ai), qf = pk4(af), qg = pk4(ag), qo = pk4(ao);
-      char* dr = da + edoc * DAROW + ul * 2;
-      *reinterpret_cast<uint2*>(dr) = qi;
-      *reinterpret_cast<uint2*>(dr + HH * 2) = qf;
-      *reinterpret_cast<uint2*>(dr + 2 * HH * 2) = qg;
-      *reinterpret_cast<uint2*>(dr + 3 * HH * 2) = qo;
-      __syncthreads();
-      // ---- partial dh for all 256 units from the own gate columns -------------------------------------------------
-      f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-      for (int ks = 0; ks < KT; ++ks) {
-        const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(da + mdoc * DAROW + (ks * 32 + 8 * g4) * 2);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[ks], bfr, acc[0], 0, 0, 0);
-        const bf16x8 w1 = (ks < KT / 2) ? wreg[KT + ks] : *reinterpret_cast<const bf16x8*>(wl + (ks - KT / 2) * 1024 + lane * 16);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, bfr, acc[1], 0, 0, 0);
-      }
-      const bool mine_half = (w / (KS / 2)) == p;        // this wave's 32 units belong to my half
-      const unsigned tag = (unsigned)(maxlen - s);
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2) {
-        const int ulw = (w % (KS / 2)) * 32 + t2 * 16 + 4 * g4;       // unit within its half
-        if (mine_half) {
-          *reinterpret_cast<float4*>(dhl + ((size_t)g * LP_DOCS + mdoc) * HH + ulw) = make_float4(acc[t2][0], acc[t2][1], acc[t2][2], acc[t2][3]);
-        } else {
-          u64* dst = xarea(g, p, s & 1) + (ulw >> 2) * 16 + mdoc;
-          const float vv[4] = {acc[t2][0], acc[t2][1], acc[t2][2], acc[t2][3]};
-          const uint2 pk = pk4(vv);
-          __hip_atomic_store(dst, ((u64)tag << 32) | pk.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(dst + NT, ((u64)tag << 32) | pk.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-      if (s - 1 >= 0) fetch_issue(g, s);                 // the partner computes its partial for my units in this same phase
-      load_in(g, s - 2, in[PAR][g]);                     // same parity buffer, consumed above
-      {
-        const int t = (d == 0) ? s : (len[g] - 1 - s);
-        bf16_t* dx = active ? dxproj + grow0[g] + (size_t)t * ldx : reinterpret_cast<bf16_t*>(dump + tid * 16);
-        *reinterpret_cast<uint2*>(dx) = qi;
-        *reinterpret_cast<uint2*>(dx + H) = qf;
-        *reinterpret_cast<uint2*>(dx + 2 * H) = qg;
-        *reinterpret_cast<uint2*>(dx + 3 * H) = qo;
-      }
-      __syncthreads();
+    char* da = dabuf + PAR * LP_DOCS * DAROW;
+    const bool active = s < len;
+    const PairBwdIn& cur = in[PAR];
+    // ---- dh = own partial + partner partial (+ dOut) -> gate pre-activation gradients; math on every lane ----------
+    uint2 oth = make_uint2(0, 0);
+    if (s + 1 <= maxlen - 1) {
+      fetch(s + 1);
+      oth = make_uint2((unsigned)v[0], (unsigned)v[1]);
     }
+    uint2 q[4];
+    {
+      const float dhv[4] = {own[0] + bf16_lo(oth.x), own[1] + bf16_hi(oth.x), own[2] + bf16_lo(oth.y), own[3] + bf16_hi(oth.y)};
+      float gi[4], gf[4], gg[4], go[4], dov[4], ai[4], af[4], ag[4], ao[4];
+      upk4(cur.gi, gi); upk4(cur.gf, gf); upk4(cur.gg, gg); upk4(cur.go, go); upk4(cur.dov, dov);
+      const float ct[4] = {cur.ct.x, cur.ct.y, cur.ct.z, cur.ct.w};
+      const bool has_prev = s > 0;                       // the first processed position has c_prev = 0
+      const float cp[4] = {has_prev ? cur.cp.x : 0.f, has_prev ? cur.cp.y : 0.f, has_prev ? cur.cp.z : 0.f, has_prev ? cur.cp.w : 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float tc = ftanh2(ct[r]);
+        const float dht = dov[r] + dhv[r];
+        const float dct = dc[r] + dht * go[r] * (1.f - tc * tc);
+        ai[r] = active ? dct * gg[r] * gi[r] * (1.f - gi[r]) : 0.f;
+        af[r] = active ? dct * cp[r] * gf[r] * (1.f - gf[r]) : 0.f;
+        ag[r] = active ? dct * gi[r] * (1.f - gg[r] * gg[r]) : 0.f;
+        ao[r] = active ? dht * tc * go[r] * (1.f - go[r]) : 0.f;
+        dc[r] = active ? dct * gf[r] : dc[r];
+      }
+      q[0] = pk4(ai); q[1] = pk4(af); q[2] = pk4(ag); q[3] = pk4(ao);
+    }
+    char* dr = da + doc * DAROW + ul * 2;
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt) *reinterpret_cast<uint2*>(dr + gt * HH * 2) = q[gt];
+    // inputs two steps ahead (same parity buffer, just consumed), then the input-projection gradients; lanes whose document
+    // has ended store to the dump area instead of branching
+    load_in(s - 2, in[PAR]);
+    {
+      const int t = (d == 0) ? s : (len - 1 - s);
+      bf16_t* dx = active ? dxproj + grow0 + (size_t)t * ldx : reinterpret_cast<bf16_t*>(dump + tid * 16);
+#pragma unroll
+      for (int gt = 0; gt < 4; ++gt) *reinterpret_cast<uint2*>(dx + gt * H) = q[gt];
+    }
+    __syncthreads();
+    // ---- partial dh from the own gate columns: tile 0 = my units (kept), tile 1 = the partner's units (posted) ------
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks) {
+      const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(da + doc * DAROW + (ks * 32 + 8 * g4) * 2);
+      const bf16x8 w1 = (ks < KT / 2) ? wreg[KT + ks] : *reinterpret_cast<const bf16x8*>(wl + (ks - KT / 2) * 1024 + lane * 16);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, bfr, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[ks], bfr, acc[0], 0, 0, 0);
+    }
+    {
+      const u64 tag = (u64)(unsigned)(maxlen - s) << 32;
+      u64* dst = xarea(p, s & 1) + tid;
+      const float vv[4] = {acc[1][0], acc[1][1], acc[1][2], acc[1][3]};
+      const uint2 pk = pk4(vv);
+      __hip_atomic_store(dst, tag | pk.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(dst + NT, tag | pk.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    own = acc[0];
+    if (s - 1 >= 0) fetch_issue(s);                      // the partner computes its partial for my units in this same phase
   };
   __builtin_amdgcn_s_waitcnt(0);                         // clean scoreboard at the loop header
   for (int s = maxlen - 1; s >= 0; s -= 2) {
@@ -596,12 +561,10 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_bwd_pair_kernel(int B, int L,
     if (s - 1 >= 0) step(std::integral_constant<int, 1>{}, s - 1);
   }
   // rows >= len: zero gradients (the GEMMs that follow read every row)
+  if (bdoc < B)
+    for (int t = len; t < L; ++t)
 #pragma unroll
-  for (int g = 0; g < LP_GROUPS; ++g)
-    if (bdoc[g] < B)
-      for (int t = len[g]; t < L; ++t)
-#pragma unroll
-        for (int gt = 0; gt < 4; ++gt) *reinterpret_cast<uint2*>(dxproj + ((size_t)bdoc[g] * L + t) * ldx + (size_t)d * 4 * H + gt * H + u) = make_uint2(0, 0);
+      for (int gt = 0; gt < 4; ++gt) *reinterpret_cast<uint2*>(dxproj + ((size_t)bdoc * L + t) * ldx + (size_t)d * 4 * H + gt * H + u) = make_uint2(0, 0);
 }
 
 // hprev[b, t] = out[b, t_prev] (zero at a document's first processed position and on padded rows), per direction
@@ -633,7 +596,7 @@ int mts_lstm_pair_bwd(hipStream_t st, int B, int L, int H, int ndir, const float
   const size_t rows4 = (size_t)B * L * ndir * H / 4;
   hipLaunchKernelGGL(lstm_hprev_kernel<bf16_t>, dim3((unsigned)((rows4 + 255) / 256)), dim3(256), 0, st, B, L, H, ndir, lengths, (const bf16_t*)out,
                      (bf16_t*)hprev);
-  const size_t lds = (size_t)LP_GROUPS * LP_DOCS * ((4 * HH + 8) * 2 + HH * 4 + HH * 2) + (size_t)KS * (KT / 2) * 1024;
+  const size_t lds = (size_t)2 * LP_DOCS * ((4 * HH + 8) * 2) + (size_t)KS * (KT / 2) * 1024;
   auto k = lstm_bwd_pair_kernel<KS>;
   static bool attr = false;
   if (!attr) {
