@@ -192,6 +192,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
         if constexpr (B_KMAJOR) bfr[i] = frag_kmajor(sb, wn * 64 + i * 16 + r16, ks * 4 + g);
         else bfr[i] = frag_strided(sb, ks * 32 + 8 * g, wn * 64 + i * 16, lane);
       }
+      if constexpr (!A_KMAJOR || !B_KMAJOR) {            // transposed reads are asm: wait for them by hand (gemm_common.h)
+        lds_frags_wait();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if constexpr (!A_KMAJOR) frag_ready(af[i]);
+          if constexpr (!B_KMAJOR) frag_ready(bfr[i]);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -576,8 +584,9 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
   const int tile_mode = g_tile_mode;
   const unsigned plain = epilogue & ~MTS_EPI_ACCUM;
   const bool can_split = (c_dtype == MTS_F32 && plain == 0 && workspace && N % 4 == 0 && K >= 2048);
-  // 256-tile kernel: K-contiguous A only (its transposed-read TN form measures slower than the 128 kernel)
-  const bool can256 = (K % BK == 0) && K >= 512 && M >= 8 && N >= 8 && tile_mode != 128 && (layout != MTS_TN || tile_mode >= 224);
+  // (until the transposed LDS reads became inline asm -- gemm_common.h -- the big tiles' TN form was slower than the 128
+  // kernel: one workgroup per CU had nothing to hide the exposed DMA wait behind; now it is the fastest weight-gradient form)
+  const bool can256 = (K % BK == 0) && K >= 512 && M >= 8 && N >= 8 && tile_mode != 128;
   const double bw = 3500.0;     // slab MB per us
   double best = 1e30;
   int splits = 1;
@@ -590,7 +599,8 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
     const int tile = big ? 256 : 128;
     // measured on MI355X (tools/gemm_ksweep.py, gemm_sweep.py): us per K element per round of workgroups, and per-round fixed cost
     const double slots = big ? 256.0 : 512.0;
-    const double t_k = (big ? (layout == MTS_TN ? 0.0353 : 0.0232) : (layout == MTS_TN ? 0.0170 : 0.0180)) * (big == 2 ? 0.875 : 1.0);
+    const double t_k = layout == MTS_TN ? (big == 2 ? 0.0210 : big == 1 ? 0.0218 : 0.0145)          // tools/gemm_tn_sweep.py
+                                        : (big ? 0.0232 * (big == 2 ? 0.875 : 1.0) : 0.0180);
     const double t_0 = big ? 7.7 : 6.5;
     const int nt = ceil_div(M, tile) * (big == 2 ? N / 224 : ceil_div(N, tile));
     for (int sp = 1; sp <= (can_split ? 32 : 1); ++sp) {

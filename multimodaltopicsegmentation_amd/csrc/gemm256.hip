@@ -182,6 +182,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GemmArgs a)
           else af[i][ks] = frag_strided(At, ks * 32 + 8 * g, i * 16, lane);
         }
       }
+      if constexpr (!A_KMAJOR || !B_KMAJOR) {            // transposed reads are asm: wait for them by hand (gemm_common.h)
+        lds_frags_wait();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) if constexpr (!B_KMAJOR) frag_ready(b0[j][ks]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) if constexpr (!A_KMAJOR) frag_ready(af[i][ks]);
+        }
+      }
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -200,6 +210,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GemmArgs a)
           if constexpr (B_KMAJOR) b1[j][ks] = frag_kmajor(Bt, bcol + 32 + j * 16 + r16, ks * 4 + g);
           else b1[j][ks] = frag_strided(Bt, ks * 32 + 8 * g, bcol + 32 + j * 16, lane);
         }
+      if constexpr (!B_KMAJOR) {
+        lds_frags_wait();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) frag_ready(b1[j][ks]);
+      }
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -220,6 +237,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GemmArgs a)
           if constexpr (A_KMAJOR) af[i][ks] = frag_kmajor(At, 64 + i * 16 + r16, ks * 4 + g);
           else af[i][ks] = frag_strided(At, ks * 32 + 8 * g, 64 + i * 16, lane);
         }
+      if constexpr (!A_KMAJOR) {
+        lds_frags_wait();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) frag_ready(af[i][ks]);
+      }
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)

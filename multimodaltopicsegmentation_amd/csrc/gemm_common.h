@@ -160,15 +160,28 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 __device__ __forceinline__ bf16x8 frag_kmajor(const char* tile, int row, int chunk) {
   return *reinterpret_cast<const bf16x8*>(tile + kmajor_off(row, chunk));
 }
-// fragment X[k = kbase + 0..7][c = c0 + (lane&15)] of a strided image through two transposed reads
+// fragment X[k = kbase + 0..7][c = c0 + (lane&15)] of a strided image through two transposed reads.
+//
+// The reads are INLINE ASM on purpose.  Written with __builtin_amdgcn_ds_read_tr16_b64 the compiler's wait-count pass cannot
+// tell them apart from the LDS range an outstanding LDS-DMA (global_load_lds) is writing, and puts "s_waitcnt vmcnt(0)" in
+// front of the first transposed read of every phase: the DMA of the NEXT K-tile, issued a few instructions earlier, had to
+// land before the current tile could be read -- no overlap of copy and MFMA inside a workgroup for every layout with a
+// strided operand (NN, TN, TT), while NT (plain ds_read_b128) was unaffected.  The asm form is invisible to that pass;
+// the price is that the consumer must wait for the data itself: lds_frags_wait() once after the last read, then
+// frag_ready(f) on every fragment read this way (an empty asm that ties the fragment to the wait's position).
 __device__ __forceinline__ bf16x8 frag_strided(const char* tile, int kbase, int c0, int lane) {
   const int r = lane & 15;
   const int q = r >> 2, p = r & 3;
   const int col = c0 + 4 * p;
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + strided_off(kbase + q, col)));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + strided_off(kbase + 4 + q, col)));
+  // rows kbase + q and kbase + 4 + q share the swizzle key (bits 0-1 and 3 of the row), so the second read is +4 rows = +1024 B
+  const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(tile + strided_off(kbase + q, col));
+  s16x4 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(addr));
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(bf16x8, v);
 }
+__device__ __forceinline__ void lds_frags_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void frag_ready(bf16x8& f) { asm volatile("" : "+v"(f)); }
 

@@ -15,7 +15,7 @@ for M, N, K in [(5376, 1792, 16384), (1792, 1792, 16384), (1792, 256, 16384), (2
     B = torch.randn(K, N, device=dev, generator=g).to(torch.bfloat16)
     out = torch.empty(M, N, device=dev)
     ref = None
-    for tile in (128,):
+    for tile in (128, 224, 256):
         for sp in (1, 2, 3, 4, 6, 8):
             L.check(L.lib.mts_set_option(b'gemm_tile', tile))
             L.check(L.lib.mts_set_option(b'gemm_splits', sp))
