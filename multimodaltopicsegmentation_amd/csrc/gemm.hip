@@ -163,22 +163,34 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
     }
   }
 
+  // LDS-DMA form: NB K-tile buffers, copies run NB-1 tiles ahead; a wave issues 8 DMA instructions per K-tile and the vector-
+  // memory counter retires in order, so "tile kt+1 has landed" = at most 8 x (tiles issued after it) instructions outstanding
+  const int NB = GLDS ? a.nbuf : 2;
+  auto wait_tiles_outstanding = [&](int n) {
+    if (n >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
   if (nk > 0) {
     if constexpr (GLDS) {
-      dma_tile(0, 0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int pre = min(NB - 1, nk);
+      for (int t = 0; t < pre; ++t) dma_tile(t, t);
+      wait_tiles_outstanding(pre - 1);
     } else {
       load_tile(0);
       store_tile(0);
     }
   }
-  __syncthreads();
+  if constexpr (GLDS) __builtin_amdgcn_s_barrier();      // (not __syncthreads(): its fence would wait for every copy in flight)
+  else __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) {
-      if constexpr (GLDS) dma_tile(kt + 1, buf ^ 1);   // lands in the other buffer while this one feeds the MFMAs
-      else load_tile(kt + 1);                          // global loads stay in flight behind the MFMAs below
+    const int buf = GLDS ? (kt & (NB - 1)) : (kt & 1);
+    if constexpr (GLDS) {
+      // lands in the buffer read one iteration ago (every wave is past that iteration's barrier) while this one feeds the MFMAs
+      if (kt + NB - 1 < nk) dma_tile(kt + NB - 1, (kt + NB - 1) & (NB - 1));
+    } else {
+      if (kt + 1 < nk) load_tile(kt + 1);              // global loads stay in flight behind the MFMAs below
     }
     const char* sa = smem + buf * (2 * TILE_BYTES);
     const char* sb = sa + TILE_BYTES;
@@ -207,11 +219,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // C^T tile
     }
     if constexpr (GLDS) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
+      wait_tiles_outstanding(max(0, min(nk - 1, kt + NB - 1) - (kt + 1)));   // this wave's pieces of tile kt+1 have landed
+      // raw barrier: __syncthreads() carries a fence that the compiler turns into "s_waitcnt vmcnt(0)", i.e. a wait for the
+      // copies of the tiles further ahead as well
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     } else {
       if (kt + 1 < nk) store_tile(buf ^ 1);
+      __syncthreads();
     }
-    __syncthreads();
   }
 
   const bool first_slice = (blockIdx.z == 0);
@@ -495,6 +511,7 @@ static int g_gemm_glds = -1;
 static int g_tile_mode = -1;
 static int g_force_splits = 0;
 static int g_tile_order = 1;
+static int g_gemm_deep = 1;      // "gemm_deep" = 0: never use the four-buffer copy pipeline of the 128x128 kernel (A/B testing)
 static int g_chain = 0;          // "gemm_chain" = 1: split-K of the 128x128 kernel accumulates in place (no slabs, no reduce launch); measured
                                  // SLOWER (532 vs 465 us on the QKV weight gradient: one agent-scope release per workgroup writes the L2 back)
 static int g_last_tile = 0, g_last_splits = 0;   // what the planner chose for the most recent bf16 mts_gemm (bench.py labels)
@@ -513,6 +530,7 @@ extern "C" int mts_set_option(const char* key, int value) {
   if (!strcmp(key, "gemm_splits")) { g_force_splits = value; return MTS_OK; }
   if (!strcmp(key, "gemm_order")) { g_tile_order = value; return MTS_OK; }
   if (!strcmp(key, "gemm_chain")) { g_chain = value; return MTS_OK; }
+  if (!strcmp(key, "gemm_deep")) { g_gemm_deep = value; return MTS_OK; }
   if (!strcmp(key, "band_mfma")) { mts_band_set_mfma(value); return MTS_OK; }
   mts_set_error("mts_set_option: unknown key %s", key);
   return MTS_ERR_INVALID;
@@ -527,8 +545,22 @@ static void launch_bf16(const GemmArgs& a, int splits, hipStream_t st) {
     g_gemm_glds = (e && e[0] == '0') ? 0 : 1;
   }
   const bool glds = g_gemm_glds && (a.K % BK == 0) && (a.ksplit % BK == 0) && a.M >= 8 && a.N >= 8;
-  if (glds) hipLaunchKernelGGL((gemm_bf16_kernel<LAYOUT, TC, true>), dim3(nt, 1, splits), dim3(256), 4 * TILE_BYTES, st, a);
-  else hipLaunchKernelGGL((gemm_bf16_kernel<LAYOUT, TC, false>), dim3(nt, 1, splits), dim3(256), 4 * TILE_BYTES, st, a);
+  if (glds) {
+    // at most one workgroup per CU: nothing but a deeper copy pipeline hides the DMA latency of a K-tile (the feed-forward
+    // projections, N or K = 256: 256 tiles, 28 K-tiles each) -- four buffers, copies three tiles ahead
+    GemmArgs b = a;
+    const bool deep = g_gemm_deep && (size_t)nt * splits <= 256 && a.ksplit >= 4 * BK;
+    b.nbuf = deep ? 4 : 2;
+    auto k = gemm_bf16_kernel<LAYOUT, TC, true>;
+    static bool attr_set = false;
+    if (deep && !attr_set) {
+      if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES) != hipSuccess) b.nbuf = 2;
+      else attr_set = true;
+    }
+    hipLaunchKernelGGL(k, dim3(nt, 1, splits), dim3(256), (b.nbuf == 4 ? 8 : 4) * TILE_BYTES, st, b);
+  } else {
+    hipLaunchKernelGGL((gemm_bf16_kernel<LAYOUT, TC, false>), dim3(nt, 1, splits), dim3(256), 4 * TILE_BYTES, st, a);
+  }
 }
 
 extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int M, int N, int K, const void* A, int lda,
@@ -547,7 +579,7 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.residual = residual; a.aux = aux;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.ldaux = ldaux;
   a.epi = epilogue; a.colscale = colscale; a.ncols_scaled = ncols_scaled;
-  a.ksplit = K; a.slab = nullptr; a.chain = nullptr; a.order = g_tile_order;
+  a.ksplit = K; a.slab = nullptr; a.chain = nullptr; a.order = g_tile_order; a.nbuf = 2;
 
   if (a_dtype == MTS_F32) {
     StrideArgs s;

@@ -14,6 +14,8 @@ struct GemmArgs {
   float colscale; int ncols_scaled;
   int ksplit;      // K elements per blockIdx.z slice (multiple of 64)
   int order;       // tile order of the persistent kernels: 1 = 4-row bands (L2-blocked), 0 = row-major
+  int nbuf;        // 128x128 kernel, LDS-DMA form: K-tile buffers in LDS (2, or 4 = copies run three K-tiles ahead; launched
+                   // with 128 KiB of LDS when the grid has at most one workgroup per CU and nothing else hides DMA latency)
   unsigned* chain; // split-K without slabs (128x128 kernel): per-tile turn counter, zeroed before the launch; slice z adds its
                    // partial tile into C when the counter reads z (fixed order -> bitwise reproducible), then bumps it
   float* slab;     // split-K: slice z stores its fp32 partial tile to slab[z][M][N] (plain stores); reduced afterwards
