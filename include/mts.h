@@ -60,7 +60,9 @@ const char* mts_last_error(void);
 /* version / build info: "mts-hip <n> gfx950" */
 const char* mts_version(void);
 /* tuning / A-B switches: "gemm_tile" = 0 (cost model) | 128 | 224 | 256 ; "gemm_glds" = 1 (LDS-DMA staging) | 0 (register
- * staging) ; "gemm_splits" = 0 (cost model) | n ; "gemm_order" = 1 (L2-blocked tile order) | 0 ; "band_mfma" = 1 | 0 */
+ * staging) ; "gemm_splits" = 0 (cost model) | n ; "gemm_order" = 1 (L2-blocked tile order) | 0 ; "gemm_chain" = 0 | 1 (split-K
+ * of the 128x128 kernel accumulates in place) ; "gemm_deep" = 1 (four-buffer copy pipeline of the 128x128 kernel for grids of at
+ * most one workgroup per CU) | 0 ; "band_mfma" = 1 | 0 */
 int mts_set_option(const char* key, int value);
 /* tile width (128 | 224 | 256) and K split the cost model chose for the most recent bf16 mts_gemm (bench / profiling labels) */
 int mts_gemm_last_plan(int* tile, int* splits);
