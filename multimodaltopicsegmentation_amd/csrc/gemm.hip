@@ -631,7 +631,7 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
     const int tile = big ? 256 : 128;
     // measured on MI355X (tools/gemm_ksweep.py, gemm_sweep.py): us per K element per round of workgroups, and per-round fixed cost
     const double slots = big ? 256.0 : 512.0;
-    const double t_k = layout == MTS_TN ? (big == 2 ? 0.0210 : big == 1 ? 0.0218 : 0.0145)          // tools/gemm_tn_sweep.py
+    const double t_k = layout == MTS_TN ? (big == 2 ? 0.0200 : big == 1 ? 0.0218 : 0.0145)          // tools/gemm_tn_sweep.py, gemm_ab.py
                                         : (big ? 0.0232 * (big == 2 ? 0.875 : 1.0) : 0.0180);
     const double t_0 = big ? 7.7 : 6.5;
     const int nt = ceil_div(M, tile) * (big == 2 ? N / 224 : ceil_div(N, tile));

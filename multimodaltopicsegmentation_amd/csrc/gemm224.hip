@@ -5,21 +5,25 @@
 // the 256 CUs -- the last round is 3/4 or 1/4 full.  224-wide tiles give 512 / 1536 tiles = exactly 2 / 6 rounds, each
 // 12.5 % shorter.
 //
-// Same pipeline as gemm256.hip (two K-tile buffers of four 16-KiB half images, LDS-DMA one K-tile ahead for A and two
-// for B behind a counted vmcnt, raw s_barrier), but the 8 waves are laid out 4 (M) x 2 (N): wave (wm, wn) owns C rows
+// Pipeline: three A images and two B images of two 16-KiB halves each, both operands copied by LDS-DMA TWO K-tiles ahead behind
+// a counted vmcnt (A one tile ahead, as in gemm256.hip, left its latency exposed at the end of every K-step), raw s_barrier;
+// the 8 waves are laid out 4 (M) x 2 (N): wave (wm, wn) owns C rows
 // wm*64..+63 (half of A[wm>>1]) and cols wn*112..+111 (all of B[wn]; a B half image holds 112 used rows, the DMA still
 // moves 128 so that every wave issues the same number of loads and one counted wait serves all):
-//     phase 1: DMA A0(t+1) ; read A[rows 0..31], B[cols 0..63]   ; 16 MFMA  (0,0)
-//     phase 2: DMA A1(t+1) ; read B[cols 64..111]                ; 12 MFMA  (0,1) ; barrier
+//     phase 1: DMA A0(t+2) ; read A[rows 0..31], B[cols 0..63]   ; 16 MFMA  (0,0)
+//     phase 2: DMA A1(t+2) ; read B[cols 64..111]                ; 12 MFMA  (0,1) ; barrier
 //     phase 3: DMA B0(t+2) ; read A[rows 32..63]                 ; 12 MFMA  (1,1)
-//     phase 4: DMA B1(t+2) ;                                       16 MFMA  (1,0) ; vmcnt(4) ; barrier
+//     phase 4: DMA B1(t+2) ;                                       16 MFMA  (1,0) ; vmcnt(8) ; barrier
 #include <algorithm>
 #include <math.h>
 #include "gemm_common.h"
 
 #define HT_BYTES 16384
-#define BUF_BYTES (4 * HT_BYTES)
-#define LDS_TOTAL (2 * BUF_BYTES + 8 * 4096)
+// LDS: three A images (2 halves each) | two B images (2 halves each); the bf16 store staging (8 waves x 4 KiB) aliases the third
+// A image, which is idle between a tile's last K-step and the next tile's first
+#define A_BYTES (2 * HT_BYTES)
+#define B_BASE (3 * A_BYTES)
+#define LDS_TOTAL (3 * A_BYTES + 4 * HT_BYTES)
 #define BN224 224
 #define HN224 112
 
@@ -119,14 +123,14 @@ template <int LAYOUT, typename TC>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a) {
   constexpr bool A_KMAJOR = (LAYOUT == MTS_NT || LAYOUT == MTS_NN);
   constexpr bool B_KMAJOR = (LAYOUT == MTS_NT || LAYOUT == MTS_TT);
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A0 | A1 | B0 | B1] + 8 x 4 KiB store staging
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [3][A0 | A1]  [2][B0 | B1]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave_u >> 1, wn = wave_u & 1;
   const int r16 = lane & 15, g = lane >> 4;
-  char* stage = smem + 2 * BUF_BYTES + wave_u * 4096;
+  char* stage = smem + 2 * A_BYTES + wave_u * 4096;
 
   const int ntn = a.N / BN224;
   const int ntm = (a.M + 255) / 256;
@@ -153,16 +157,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a)
     bn0 = (within / rows) * BN224;
   };
   int bm0, bn0;
-  auto dmaA = [&](int h, int kt) {
-    dma_half<A_KMAJOR>(A, a.lda, bm0 + h * 128, a.M, kbeg + kt * BK, smem + (kt & 1) * BUF_BYTES + h * HT_BYTES, wave_u, lane);
+  // A(kt) lives in A image kt % 3 (`ab`), B(kt) in B image kt & 1; both are copied TWO K-tiles ahead
+  auto dmaA = [&](int h, int kt, int ab) {
+    dma_half<A_KMAJOR>(A, a.lda, bm0 + h * 128, a.M, kbeg + kt * BK, smem + ab * A_BYTES + h * HT_BYTES, wave_u, lane);
   };
   auto dmaB = [&](int h, int kt) {
-    dma_half<B_KMAJOR>(B, a.ldb, bn0 + h * HN224, a.N, kbeg + kt * BK, smem + (kt & 1) * BUF_BYTES + (2 + h) * HT_BYTES, wave_u, lane);
+    dma_half<B_KMAJOR>(B, a.ldb, bn0 + h * HN224, a.N, kbeg + kt * BK, smem + B_BASE + ((kt & 1) * 2 + h) * HT_BYTES, wave_u, lane);
   };
   auto prologue = [&]() {
     if (nk > 0) {
-      dmaB(0, 0); dmaB(1, 0); dmaA(0, 0); dmaA(1, 0);
-      if (nk > 1) { dmaB(0, 1); dmaB(1, 1); }
+      dmaB(0, 0); dmaB(1, 0); dmaA(0, 0, 0); dmaA(1, 0, 0);
+      if (nk > 1) { dmaB(0, 1); dmaB(1, 1); dmaA(0, 1, 1); dmaA(1, 1, 1); }
     }
   };
 
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a)
   if (t >= nt) return;
   tile_origin(t, bm0, bn0);
   prologue();
-  if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // K-tile 0 has landed (a wave issues 8 copy instructions per K-tile)
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
@@ -187,12 +192,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a)
 #pragma unroll
       for (int j = 0; j < 7; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    int ab = 0;                                   // kt % 3
     for (int kt = 0; kt < nk; ++kt) {
-      const char* At = smem + (kt & 1) * BUF_BYTES + (wm >> 1) * HT_BYTES;
-      const char* Bt = smem + (kt & 1) * BUF_BYTES + (2 + wn) * HT_BYTES;
+      const char* At = smem + ab * A_BYTES + (wm >> 1) * HT_BYTES;
+      const char* Bt = smem + B_BASE + ((kt & 1) * 2 + wn) * HT_BYTES;
+      const int ab2 = ab == 0 ? 2 : ab - 1;       // (kt + 2) % 3: the A image read one K-step ago
 
       // ---- phase 1 ---------------------------------------------------------------------------
-      if (kt + 1 < nk) dmaA(0, kt + 1);
+      if (kt + 2 < nk) dmaA(0, kt + 2, ab2);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a)
       __builtin_amdgcn_s_setprio(0);
 
       // ---- phase 2 ---------------------------------------------------------------------------
-      if (kt + 1 < nk) dmaA(1, kt + 1);
+      if (kt + 2 < nk) dmaA(1, kt + 2, ab2);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -287,10 +294,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j][ks], af[i][ks], acc[2 + i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
-      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but B(kt+2) have landed
+      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // all but A(kt+2), B(kt+2) have landed
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      ab = ab == 2 ? 0 : ab + 1;
     }
 
     const int m0 = bm0 + wm * 64, n0 = bn0 + wn * HN224;
