@@ -3,7 +3,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multimodaltopicsegmentation_amd import ops
-B, L, H = 64, 256, 256
+B, L, H = int(os.environ.get("MTS_B", 64)), int(os.environ.get("MTS_L", 256)), 256
 dev = 'cuda'
 g = torch.Generator(device=dev).manual_seed(0)
 xproj = (torch.randn(B * L, 8 * H, device=dev, generator=g) * 0.5).to(torch.bfloat16)
