@@ -197,19 +197,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[4], bfr[4];
+      frag_raw ra4[4], rb4[4];                           // transposed reads in flight (strided operands only)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if constexpr (A_KMAJOR) af[i] = frag_kmajor(sa, wm * 64 + i * 16 + r16, ks * 4 + g);
-        else af[i] = frag_strided(sa, ks * 32 + 8 * g, wm * 64 + i * 16, lane);
+        else ra4[i] = frag_strided(sa, ks * 32 + 8 * g, wm * 64 + i * 16, lane);
         if constexpr (B_KMAJOR) bfr[i] = frag_kmajor(sb, wn * 64 + i * 16 + r16, ks * 4 + g);
-        else bfr[i] = frag_strided(sb, ks * 32 + 8 * g, wn * 64 + i * 16, lane);
+        else rb4[i] = frag_strided(sb, ks * 32 + 8 * g, wn * 64 + i * 16, lane);
       }
       if constexpr (!A_KMAJOR || !B_KMAJOR) {            // transposed reads are asm: wait for them by hand (gemm_common.h)
         lds_frags_wait();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          if constexpr (!A_KMAJOR) frag_ready(af[i]);
-          if constexpr (!B_KMAJOR) frag_ready(bfr[i]);
+          if constexpr (!A_KMAJOR) af[i] = frag_finish(ra4[i]);
+          if constexpr (!B_KMAJOR) bfr[i] = frag_finish(rb4[i]);
         }
       }
 #pragma unroll

@@ -146,6 +146,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GemmArgs a)
 
   f32x4 acc[8][4];
   bf16x8 af[4][2], b0[2][2], b1[2][2];
+  frag_raw raf[4][2], rb0[2][2], rb1[2][2];      // transposed reads in flight (strided operands only; gemm_common.h)
   const int bcol = (wn & 1) * 64;
 
   int t = blockIdx.x;
@@ -174,12 +175,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GemmArgs a)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           if constexpr (B_KMAJOR) b0[j][ks] = frag_kmajor(Bt, bcol + j * 16 + r16, ks * 4 + g);
-          else b0[j][ks] = frag_strided(Bt, ks * 32 + 8 * g, bcol + j * 16, lane);
+          else rb0[j][ks] = frag_strided(Bt, ks * 32 + 8 * g, bcol + j * 16, lane);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if constexpr (A_KMAJOR) af[i][ks] = frag_kmajor(At, i * 16 + r16, ks * 4 + g);
-          else af[i][ks] = frag_strided(At, ks * 32 + 8 * g, i * 16, lane);
+          else raf[i][ks] = frag_strided(At, ks * 32 + 8 * g, i * 16, lane);
         }
       }
       if constexpr (!A_KMAJOR || !B_KMAJOR) {            // transposed reads are asm: wait for them by hand (gemm_common.h)
@@ -187,9 +188,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GemmArgs a)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-          for (int j = 0; j < 2; ++j) if constexpr (!B_KMAJOR) frag_ready(b0[j][ks]);
+          for (int j = 0; j < 2; ++j) if constexpr (!B_KMAJOR) b0[j][ks] = frag_finish(rb0[j][ks]);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) if constexpr (!A_KMAJOR) frag_ready(af[i][ks]);
+          for (int i = 0; i < 4; ++i) if constexpr (!A_KMAJOR) af[i][ks] = frag_finish(raf[i][ks]);
         }
       }
       __builtin_amdgcn_s_setprio(1);
@@ -208,14 +209,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GemmArgs a)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           if constexpr (B_KMAJOR) b1[j][ks] = frag_kmajor(Bt, bcol + 32 + j * 16 + r16, ks * 4 + g);
-          else b1[j][ks] = frag_strided(Bt, ks * 32 + 8 * g, bcol + 32 + j * 16, lane);
+          else rb1[j][ks] = frag_strided(Bt, ks * 32 + 8 * g, bcol + 32 + j * 16, lane);
         }
       if constexpr (!B_KMAJOR) {
         lds_frags_wait();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) frag_ready(b1[j][ks]);
+          for (int j = 0; j < 2; ++j) b1[j][ks] = frag_finish(rb1[j][ks]);
       }
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -235,14 +236,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GemmArgs a)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if constexpr (A_KMAJOR) af[i][ks] = frag_kmajor(At, 64 + i * 16 + r16, ks * 4 + g);
-          else af[i][ks] = frag_strided(At, ks * 32 + 8 * g, 64 + i * 16, lane);
+          else raf[i][ks] = frag_strided(At, ks * 32 + 8 * g, 64 + i * 16, lane);
         }
       if constexpr (!A_KMAJOR) {
         lds_frags_wait();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) frag_ready(af[i][ks]);
+          for (int i = 0; i < 4; ++i) af[i][ks] = frag_finish(raf[i][ks]);
       }
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll

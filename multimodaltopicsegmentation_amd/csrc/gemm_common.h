@@ -170,20 +170,28 @@ __device__ __forceinline__ bf16x8 frag_kmajor(const char* tile, int row, int chu
 // land before the current tile could be read -- no overlap of copy and MFMA inside a workgroup for every layout with a
 // strided operand (NN, TN, TT), while NT (plain ds_read_b128) was unaffected.  The asm form is invisible to that pass;
 // the price is that the consumer must wait for the data itself: lds_frags_wait() once after the last read, then
-// frag_ready(f) on every fragment read this way (an empty asm that ties the fragment to the wait's position).
-__device__ __forceinline__ bf16x8 frag_strided(const char* tile, int kbase, int c0, int lane) {
+// frag_finish(raw) on every fragment read this way (an empty asm ties the halves to the wait's position).
+// The two halves stay SEPARATE values until frag_finish(): assembling the four-register MFMA operand right after the asm
+// would let the compiler place register copies between the read and the wait (i.e. copy registers the LDS has not written
+// yet) whenever it cannot coalesce the halves into the tuple.
+struct frag_raw { s16x4 lo, hi; };
+__device__ __forceinline__ frag_raw frag_strided(const char* tile, int kbase, int c0, int lane) {
   const int r = lane & 15;
   const int q = r >> 2, p = r & 3;
   const int col = c0 + 4 * p;
   // rows kbase + q and kbase + 4 + q share the swizzle key (bits 0-1 and 3 of the row), so the second read is +4 rows = +1024 B
   const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(tile + strided_off(kbase + q, col));
-  s16x4 lo, hi;
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(addr));
+  frag_raw f;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(addr));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(f.hi) : "v"(addr));
+  return f;
+}
+// after lds_frags_wait(): ties both halves to the wait's position (empty asm), then forms the MFMA operand
+__device__ __forceinline__ bf16x8 frag_finish(frag_raw f) {
+  asm volatile("" : "+v"(f.lo), "+v"(f.hi));
   typedef __attribute__((ext_vector_type(8))) short s16x8;
-  s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  s16x8 v = __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(bf16x8, v);
 }
 __device__ __forceinline__ void lds_frags_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void frag_ready(bf16x8& f) { asm volatile("" : "+v"(f)); }
 
