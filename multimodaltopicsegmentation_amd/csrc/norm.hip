@@ -187,15 +187,29 @@ __global__ __launch_bounds__(256) void head_bwd_data_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------------
 // WIDE (D > 2048): blockIdx.y picks a chunk of NV*256 columns whose dx / column sums this workgroup produces; the row
 // statistics s1, s2 need the whole row, so the other chunks are read once more for them.
-template <typename T, int NV, bool WIDE>
+// FULL (D == NV * 256, e.g. 1792 = 7 x 256): every lane owns a valid column in every slot, so the per-slot bounds checks go away --
+// with them the divergent branches around the loads and stores, behind which the compiler waits for ALL outstanding memory
+// operations (the next row's prefetch, the previous slot's store acknowledgement) before every slot.
+template <typename T, int NV, bool WIDE, bool FULL = false>
 __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
     const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ dlogit, const float* __restrict__ head_w, int n_out,
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd, int rows, int D,
     T* __restrict__ dx, float* __restrict__ partial) {
   __shared__ float red[ROW_WAVES][3][64 * 4];   // one vector slot at a time is combined through LDS
+  // gamma and the head weights of this workgroup's columns live in LDS for the whole kernel: row-invariant, too many for the
+  // register file, and as global loads inside the row loop every one of them made the compiler wait for the next row's prefetch
+  __shared__ __attribute__((aligned(16))) float gam_s[NV * 256];
+  __shared__ __attribute__((aligned(16))) float hw_s[4][NV * 256];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int col0 = WIDE ? (int)blockIdx.y * (NV * 256) : 0;
+  for (int idx = threadIdx.x; idx < NV * 256; idx += 64 * ROW_WAVES) {
+    const int e = col0 + idx;
+    gam_s[idx] = (e < D) ? gamma[e] : 0.f;
+    if (head_w)
+      for (int c = 0; c < n_out; ++c) hw_s[c][idx] = (e < D) ? head_w[(size_t)c * D + e] : 0.f;
+  }
+  __syncthreads();
   float dg[NV][4], db[NV][4], dxs[NV][4];
 #pragma unroll
   for (int i = 0; i < NV; ++i)
@@ -208,11 +222,20 @@ __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
   const int stride = gridDim.x * ROW_WAVES;
   int row = blockIdx.x * ROW_WAVES + wave;
   Pack<T, 4> px[NV], pd[NV];
+  // the row's statistics and head gradients travel with the prefetch (unconditional loads from a pointer that is always valid),
+  // so that the wait for them at the top of the next iteration is a counted one that leaves this row's stores in flight
+  float mu_n = 0.f, rs_n = 0.f, dl_n[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* dlp = head_w ? dlogit : mean;
+  const int dl_mul = head_w ? n_out : 1, dl_max = head_w ? n_out - 1 : 0;
   auto fetch = [&](int r) {
+    mu_n = mean[r];
+    rs_n = rstd[r];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dl_n[c] = dlp[(size_t)r * dl_mul + min(c, dl_max)];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int e = col0 + 4 * (lane + 64 * i);
-      if (e < D) {
+      if (FULL || e < D) {
         px[i].load(x + (size_t)r * D + e);
         if (dy) pd[i].load(dy + (size_t)r * D + e);
       }
@@ -220,15 +243,14 @@ __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
   };
   if (row < rows) fetch(row);
   for (; row < rows; row += stride) {
-    const float mu = mean[row], rs = rstd[row];
+    const float mu = mu_n, rs = rs_n;
     float xh[NV][4], gy[NV][4];
     float s1 = 0.f, s2 = 0.f;
-    float dl[4] = {0.f, 0.f, 0.f, 0.f};
-    if (head_w) for (int c = 0; c < n_out; ++c) dl[c] = dlogit[(size_t)row * n_out + c];
+    const float dl[4] = {dl_n[0], dl_n[1], dl_n[2], dl_n[3]};
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int e = col0 + 4 * (lane + 64 * i);
-      if (e < D) {
+      if (FULL || e < D) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { xh[i][j] = px[i].get(j); gy[i][j] = dy ? pd[i].get(j) : 0.f; }
       }
@@ -237,15 +259,16 @@ __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int e = col0 + 4 * (lane + 64 * i);
-      if (e < D) {
-        float dv[4], gv[4];
-        load4<float>(gamma + e, gv);          // L1/L2-resident; keeping gamma in registers would cost NV*4 VGPRs
+      if (FULL || e < D) {
+        float dv[4];
+        const float4 g4v = *reinterpret_cast<const float4*>(gam_s + (e - col0));
+        const float gv[4] = {g4v.x, g4v.y, g4v.z, g4v.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) dv[j] = gy[i][j];
         if (head_w) {
           for (int c = 0; c < n_out; ++c) {
-            float wv[4];
-            load4<float>(head_w + (size_t)c * D + e, wv);
+            const float4 w4v = *reinterpret_cast<const float4*>(hw_s[c] + (e - col0));
+            const float wv[4] = {w4v.x, w4v.y, w4v.z, w4v.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) dv[j] += dl[c] * wv[j];
           }
@@ -270,7 +293,7 @@ __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
           const int e = oc * (NV * 256) + 4 * (lane + 64 * i);
-          if (e < D) {
+          if (FULL || e < D) {
             float xv[4], dv[4] = {0.f, 0.f, 0.f, 0.f}, gv[4];
             load4<T>(x + (size_t)row * D + e, xv);
             if (dy) load4<T>(dy + (size_t)row * D + e, dv);
@@ -294,7 +317,7 @@ __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int e = col0 + 4 * (lane + 64 * i);
-      if (e < D) {
+      if (FULL || e < D) {
         float o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -321,7 +344,7 @@ __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
     for (int t = threadIdx.x; t < 3 * 256; t += 64 * ROW_WAVES) {
       const int slot = t / 256, col = t % 256;
       const int e = col0 + 256 * i + col;
-      if (e < D) {
+      if (FULL || e < D) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < ROW_WAVES; ++w) s += red[w][slot][col];
@@ -581,8 +604,12 @@ static int ln_bwd_launch(hipStream_t st, int rows, int D, const void* x, const v
   if (nv <= 8) {
     dispatch_nv8(nv, [&](auto nvc) {
       constexpr int NV = decltype(nvc)::value;
-      hipLaunchKernelGGL((ln_bwd_kernel<T, NV, false>), dim3(blocks), dim3(64 * ROW_WAVES), 0, st, (const T*)x, (const T*)dy, dlogit, head_w, n_out,
-                         gamma, mean, rstd, rows, D, (T*)dx, (float*)partial);
+      if (D == NV * 256)
+        hipLaunchKernelGGL((ln_bwd_kernel<T, NV, false, true>), dim3(blocks), dim3(64 * ROW_WAVES), 0, st, (const T*)x, (const T*)dy, dlogit, head_w,
+                           n_out, gamma, mean, rstd, rows, D, (T*)dx, (float*)partial);
+      else
+        hipLaunchKernelGGL((ln_bwd_kernel<T, NV, false>), dim3(blocks), dim3(64 * ROW_WAVES), 0, st, (const T*)x, (const T*)dy, dlogit, head_w, n_out,
+                           gamma, mean, rstd, rows, D, (T*)dx, (float*)partial);
     });
   } else {   // 2048 < D <= 4096 (e.g. 768 + 1536 = 2304): two column chunks of 2048
     hipLaunchKernelGGL((ln_bwd_kernel<T, 8, true>), dim3(blocks, ceil_div(D, 2048)), dim3(64 * ROW_WAVES), 0, st, (const T*)x, (const T*)dy, dlogit,
