@@ -55,7 +55,9 @@ template <int NV> __device__ __forceinline__ void row_stats(const float (&x)[NV]
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NV, bool EMBED>
+// FULL (D == NV * 256): no per-slot bounds checks, hence no divergent branches around the loads -- behind such a branch the
+// compiler waits for every outstanding load before the next slot (seven serial HBM round trips per row at D = 1792).
+template <typename T, int NV, bool EMBED, bool FULL = false>
 __global__ __launch_bounds__(64 * ROW_WAVES) void ln_fwd_kernel(
     const void* __restrict__ xin, const float* __restrict__ pos, int pos_offset, int L, const float* __restrict__ type0,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int rows, int D,
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(64 * ROW_WAVES) void ln_fwd_kernel(
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int e = 4 * (lane + 64 * i);
-      if (e < D) {
+      if (FULL || e < D) {
         float a[4], b[4], c[4];
         load4<float>(xr + e, a); load4<float>(pr + e, b); load4<float>(type0 + e, c);
 #pragma unroll
@@ -88,41 +90,52 @@ __global__ __launch_bounds__(64 * ROW_WAVES) void ln_fwd_kernel(
     }
     if (pre) {
 #pragma unroll
-      for (int i = 0; i < NV; ++i) { const int e = 4 * (lane + 64 * i); if (e < D) store4<T>(pre + (size_t)row * D + e, x[i]); }
+      for (int i = 0; i < NV; ++i) { const int e = 4 * (lane + 64 * i); if (FULL || e < D) store4<T>(pre + (size_t)row * D + e, x[i]); }
     }
   } else {
     const T* xr = reinterpret_cast<const T*>(xin) + (size_t)row * D;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int e = 4 * (lane + 64 * i);
-      if (e < D) load4<T>(xr + e, x[i]);
+      if (FULL || e < D) load4<T>(xr + e, x[i]);
       else { x[i][0] = x[i][1] = x[i][2] = x[i][3] = 0.f; }
     }
   }
-  float mean, rstd;
-  row_stats<NV>(x, D, lane, mean, rstd, eps);
-  float hs[4] = {0.f, 0.f, 0.f, 0.f};
+  // gamma / beta for every slot are requested before the row statistics are reduced (their latency hides behind it)
+  float gv[NV][4], bv[NV][4];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int e = 4 * (lane + 64 * i);
-    if (e < D) {
-      float g[4], b[4], o[4];
-      load4<float>(gamma + e, g); load4<float>(beta + e, b);
+    if (FULL || e < D) { load4<float>(gamma + e, gv[i]); load4<float>(beta + e, bv[i]); }
+  }
+  float mean, rstd;
+  row_stats<NV>(x, D, lane, mean, rstd, eps);
+  // Two passes: every load (gamma, beta, head weights) comes before the first store.  The vector-memory counter retires in
+  // order, so a load issued after a store cannot be waited for without also waiting for the store's acknowledgement.
+  float hs[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* hwp = head_w ? head_w : gamma;                 // always-valid pointer: the head loads are unconditional
+  const int hw_max = head_w ? n_out - 1 : 0;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = (x[i][j] - mean) * rstd * g[j] + b[j];
-      store4<T>(y + (size_t)row * D + e, o);
-      if (head_w) {  // fused tagger head on the value that was stored (storage precision)
+  for (int i = 0; i < NV; ++i) {
+    const int e = 4 * (lane + 64 * i);
+    if (FULL || e < D) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[i][j] = (x[i][j] - mean) * rstd * gv[i][j] + bv[i][j];
+      if (head_w) {  // fused tagger head on the value that will be stored (storage precision)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          if (c < n_out) {
-            float w[4];
-            load4<float>(head_w + (size_t)c * D + e, w);
+          float w[4];
+          load4<float>(hwp + (size_t)min(c, hw_max) * D + e, w);   // rows past n_out repeat the last one; their sums are not used
 #pragma unroll
-            for (int j = 0; j < 4; ++j) hs[c] += to_f32(from_f32<T>(o[j])) * w[j];
-          }
+          for (int j = 0; j < 4; ++j) hs[c] += to_f32(from_f32<T>(x[i][j])) * w[j];
         }
       }
     }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int e = 4 * (lane + 64 * i);
+    if (FULL || e < D) store4<T>(y + (size_t)row * D + e, x[i]);
   }
   if (lane == 0 && mean_out) { mean_out[row] = mean; rstd_out[row] = rstd; }
   if (head_w) {
@@ -555,8 +568,12 @@ static int ln_fwd_launch(hipStream_t st, const void* x, const float* pos, int po
   dim3 grid(ceil_div(rows, ROW_WAVES)), block(64 * ROW_WAVES);
   dispatch_nv(nv, [&](auto nvc) {
     constexpr int NV = decltype(nvc)::value;
-    hipLaunchKernelGGL((ln_fwd_kernel<T, NV, EMBED>), grid, block, 0, st, x, pos, pos_offset, L, type0, gamma, beta, eps, rows, D, (T*)y,
-                       (T*)pre, mean, rstd, head_w, head_b, n_out, scores, row_src);
+    if (D == NV * 256)
+      hipLaunchKernelGGL((ln_fwd_kernel<T, NV, EMBED, true>), grid, block, 0, st, x, pos, pos_offset, L, type0, gamma, beta, eps, rows, D, (T*)y,
+                         (T*)pre, mean, rstd, head_w, head_b, n_out, scores, row_src);
+    else
+      hipLaunchKernelGGL((ln_fwd_kernel<T, NV, EMBED>), grid, block, 0, st, x, pos, pos_offset, L, type0, gamma, beta, eps, rows, D, (T*)y,
+                         (T*)pre, mean, rstd, head_w, head_b, n_out, scores, row_src);
   });
   MTS_LAUNCH_CHECK("layernorm_fwd");
   return MTS_OK;
