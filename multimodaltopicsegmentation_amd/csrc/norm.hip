@@ -368,7 +368,9 @@ __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
 }
 
 // head parameter gradient: dw[c,:] = sum_r ds[r,c] x[r,:]   (slab slots 0..3 = c); db handled by the final kernel
-template <typename T, int NV>
+// FULL (D == NV * 256, one column chunk): no bounds checks, hence no divergent branches around the loads (see ln_bwd_kernel);
+// the next row (x and its head gradients) is fetched before the current one is accumulated.
+template <typename T, int NV, bool FULL = false>
 __global__ __launch_bounds__(64 * ROW_WAVES) void head_bwd_params_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ ds,
                                                                        int n_out, int rows, int D, float* __restrict__ partial) {
   __shared__ float red[ROW_WAVES][4][64 * 4];
@@ -383,23 +385,39 @@ __global__ __launch_bounds__(64 * ROW_WAVES) void head_bwd_params_kernel(const T
 #pragma unroll
       for (int j = 0; j < 4; ++j) dw[c][i][j] = 0.f;
   float dbs[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int row = blockIdx.x * ROW_WAVES + wave; row < rows; row += gridDim.x * ROW_WAVES) {
-    float dl[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; c < n_out; ++c) dl[c] = ds[(size_t)row * n_out + c];
+  Pack<T, 4> px[NV];
+  float dl_n[4] = {0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](int r) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) dbs[c] += dl[c];
+    for (int c = 0; c < 4; ++c) dl_n[c] = ds[(size_t)r * n_out + min(c, n_out - 1)];   // unconditional; columns >= n_out are zeroed at use
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int e = col0 + 4 * (lane + 64 * i);
-      if (e < D) {
-        float xv[4];
-        load4<T>(x + (size_t)row * ldx + e, xv);
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) dw[c][i][j] += dl[c] * xv[j];
-      }
+      if (FULL || e < D) px[i].load(x + (size_t)r * ldx + e);
     }
+  };
+  const int stride = gridDim.x * ROW_WAVES;
+  int row = blockIdx.x * ROW_WAVES + wave;
+  if (row < rows) fetch(row);
+  for (; row < rows; row += stride) {
+    float dl[4], xv[NV][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dl[c] = (c < n_out) ? dl_n[c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = col0 + 4 * (lane + 64 * i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xv[i][j] = (FULL || e < D) ? px[i].get(j) : 0.f;
+    }
+    if (row + stride < rows) fetch(row + stride);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dbs[c] += dl[c];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dw[c][i][j] += dl[c] * xv[i][j];
   }
   // slab: [block][5][D] -> slots 0..3 dw rows, slot 4: first 4 entries = db partial of this workgroup
   float* slab = partial + (size_t)blockIdx.x * 5 * D;
@@ -689,14 +707,22 @@ extern "C" int mts_head_bwd_params(void* stream, int dtype, int rows, int D, int
   if (dtype == MTS_F32) {
     dispatch_nv8(nv, [&](auto nvc) {
       constexpr int NV = decltype(nvc)::value;
-      hipLaunchKernelGGL((head_bwd_params_kernel<float, NV>), dim3(blocks, chunks), dim3(64 * ROW_WAVES), 0, st, (const float*)x, ldx, dscores, n_out,
-                         rows, D, (float*)partial);
+      if (D == NV * 256)
+        hipLaunchKernelGGL((head_bwd_params_kernel<float, NV, true>), dim3(blocks, chunks), dim3(64 * ROW_WAVES), 0, st, (const float*)x, ldx, dscores,
+                           n_out, rows, D, (float*)partial);
+      else
+        hipLaunchKernelGGL((head_bwd_params_kernel<float, NV>), dim3(blocks, chunks), dim3(64 * ROW_WAVES), 0, st, (const float*)x, ldx, dscores, n_out,
+                           rows, D, (float*)partial);
     });
   } else if (dtype == MTS_BF16) {
     dispatch_nv8(nv, [&](auto nvc) {
       constexpr int NV = decltype(nvc)::value;
-      hipLaunchKernelGGL((head_bwd_params_kernel<bf16_t, NV>), dim3(blocks, chunks), dim3(64 * ROW_WAVES), 0, st, (const bf16_t*)x, ldx, dscores, n_out,
-                         rows, D, (float*)partial);
+      if (D == NV * 256)
+        hipLaunchKernelGGL((head_bwd_params_kernel<bf16_t, NV, true>), dim3(blocks, chunks), dim3(64 * ROW_WAVES), 0, st, (const bf16_t*)x, ldx, dscores,
+                           n_out, rows, D, (float*)partial);
+      else
+        hipLaunchKernelGGL((head_bwd_params_kernel<bf16_t, NV>), dim3(blocks, chunks), dim3(64 * ROW_WAVES), 0, st, (const bf16_t*)x, ldx, dscores, n_out,
+                           rows, D, (float*)partial);
     });
   } else { mts_set_error("mts_head_bwd_params: bad dtype %d", dtype); return MTS_ERR_INVALID; }
   float* rowp[4] = {nullptr, nullptr, nullptr, nullptr};
