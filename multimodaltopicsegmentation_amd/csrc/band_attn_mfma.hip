@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256, OCC) void band_mfma_bwd_q_kernel(const BandArg
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int c = 16 * kb + 4 * g + r - 16 * qb - l15;
-        pr[kb][qb][r] = (i < L && c >= 0 && c < W) ? prow[c] : 0.f;
+        pr[kb][qb][r] = (i < L && c >= 0 && c < W) ? prow[c] : 0.f;   // (the unconditional-load form of load_coef_T measured slower HERE)
       }
   }
   f32x4 acc[NKB][2];
@@ -372,7 +372,10 @@ __device__ __forceinline__ void load_coef_T(const float* __restrict__ X, size_t 
       for (int e = 0; e < 8; ++e) {
         const int i = ibase + 32 * s + 8 * g + e, c = j - i + w;
         const bool ok = i >= 0 && i < L && j < L && c >= 0 && c < W;
-        float x = ok ? X[(size_t)i * row_stride + c] : 0.f;
+        // unconditional load from a clamped (always valid) address, then a select: a load inside a divergent branch makes the
+        // compiler wait for every outstanding memory operation before the next one (32 serial round trips here)
+        float x = X[(size_t)min(max(i, 0), L - 1) * row_stride + min(max(c, 0), W - 1)];
+        x = ok ? x : 0.f;
         if (dropped && ok) x = band_keep(a, base_row + i, h, c) ? x * a.drop_scale : 0.f;        // dV sees the dropped probabilities
         v[s][nb][e] = x;
       }
