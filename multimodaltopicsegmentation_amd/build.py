@@ -20,7 +20,9 @@ def _newer(a, b):
 
 def _compile(src):
     obj = os.path.join(CSRC, src.replace('.hip', '.o'))
-    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(HERE, '..', 'include', 'mts.h')]
+    # every header of csrc/ is a dependency of every source (cheap, and no stale object when a shared header changes)
+    deps = [os.path.join(CSRC, src), os.path.join(HERE, '..', 'include', 'mts.h')]
+    deps += [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith('.h')]
     if any(_newer(d, obj) for d in deps):
         cmd = ['hipcc', *FLAGS, '-c', os.path.join(CSRC, src), '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)

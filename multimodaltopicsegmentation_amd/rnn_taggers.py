@@ -149,9 +149,14 @@ class _RnnTaggerBase(_TaggerBase):
         self.dropout_in, self.dropout_out = float(dropout_in), float(dropout_out)
         self._drop_calls = 0
         if not LSTM:
-            raise NotImplementedError('GRU (NeuralArchitectures.py:46-50) is listed as "next" in SURVEY.md §8f')
+            # dead upstream (fixture tests/golden/g15_adjacent_encoders.npz): RNN.forward hands nn.GRU an (h0, c0) tuple
+            # (NeuralArchitectures.py:104-113) -> AttributeError: 'tuple' object has no attribute 'index_select' on every call
+            raise NotImplementedError('GRU (LSTM=False, NeuralArchitectures.py:46-50): the reference itself raises AttributeError on '
+                                      'every tagger call with this option; there is no behaviour to reproduce')
         if not bidirectional:
-            raise NotImplementedError('unidirectional RNN (NeuralArchitectures.py:134-145) is listed as "next" in SURVEY.md §8f')
+            # dead upstream (g15): :134-145 returns the PackedSequence un-padded -> TypeError in the tagger's nn.Linear
+            raise NotImplementedError('unidirectional RNN (bidirectional=False, NeuralArchitectures.py:134-145): the reference itself '
+                                      'raises TypeError (PackedSequence handed to nn.Linear) on every tagger call with this option')
 
     def _prep_input(self, xs, lengths):
         """pad_packed_sequence semantics: the output covers max(lengths) positions (NeuralArchitectures.py:115)."""
@@ -252,7 +257,8 @@ class BiLSTM(_RnnTaggerBase):
     def loss(self, xs, lengths, tags, segments=None):
         """models/CRF.py:319-356 (segments / cosine auxiliary loss: SURVEY.md §8f 'next')."""
         if segments is not None:
-            raise NotImplementedError('cosine auxiliary loss (models/CRF.py:23-92) is listed as "next" in SURVEY.md §8f')
+            raise NotImplementedError('cosine auxiliary loss (models/CRF.py:23-92): no collater of the reference produces '
+                                      "batch['src_segments'] (TextSegmenter.training_step raises KeyError upstream, fixture g15)")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self._flat_params.values()):
             return self._autograd_loss(lambda: self.loss_and_grad(xs, lengths, tags, True)[0])
         return self.loss_and_grad(xs, lengths, tags, False)[0].clone()
@@ -308,6 +314,7 @@ class BiLSTMLateFusion(_RnnTaggerBase):
         side = self._side_stream(x1.device) if (self.concurrent_encoders and self._grad_hook is None) else None
         if side is not None:
             main = torch.cuda.current_stream(x1.device)
+            self._weights()                            # a stale bf16 mirror is re-cast HERE, on the main stream, ahead of both encoders
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 h2, s2 = self._rnn2.forward(self._drop_in(self._to_act(xb), 'r2'), li32, B, Lq)
@@ -349,6 +356,7 @@ class BiLSTMLateFusion(_RnnTaggerBase):
             side = self._side_stream(dev) if (self.concurrent_encoders and self._grad_hook is None) else None
             if side is not None:
                 main = torch.cuda.current_stream(dev)
+                self._weights()                        # see _fwd: never let the side stream be the one that refreshes the mirror
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     self._rnn2.backward(st['s2'], d2, st['li32'], B, Lq)
@@ -362,7 +370,8 @@ class BiLSTMLateFusion(_RnnTaggerBase):
     def loss(self, x1, x2, lengths, tags, segments=None):
         """models/CRF.py:420-461."""
         if segments is not None:
-            raise NotImplementedError('cosine auxiliary loss (models/CRF.py:23-92) is listed as "next" in SURVEY.md §8f')
+            raise NotImplementedError('cosine auxiliary loss (models/CRF.py:23-92): no collater of the reference produces '
+                                      "batch['src_segments'] (TextSegmenter.training_step raises KeyError upstream, fixture g15)")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self._flat_params.values()):
             return self._autograd_loss(lambda: self.loss_and_grad(x1, x2, lengths, tags, True)[0])
         return self.loss_and_grad(x1, x2, lengths, tags, False)[0].clone()

@@ -96,11 +96,18 @@ class _TaggerBase(FlatModule):
         self._wcopy_version = None
 
     # ---- weights in compute precision ----------------------------------------------------------
+    def _weights_version(self):
+        """Staleness signal of the bf16 mirror.  The flat buffer's own version counter is NOT enough: after ``_reflatten``
+        (every .to()/.cuda()) each parameter is re-pointed with ``p.data = view`` and keeps a version counter of its own, so an
+        in-place write through the parameter (torch optimizers, load_state_dict) no longer bumps ``_flat._version``.  Writes
+        through raw pointers (the fused optimizer kernels) bump nothing: NativeTrainer calls mark_weights_synced()."""
+        return (self._flat._version, sum(p._version for p in self._flat_params.values()))
+
     def _weights(self):
         """flat buffer in the compute dtype (bf16 mirror refreshed when the fp32 master changed)."""
         if self.compute_dtype == torch.float32:
             return self._flat
-        ver = self._flat._version
+        ver = self._weights_version()
         if self._wcopy is None or self._wcopy.device != self._flat.device:
             self._wcopy = torch.empty(self._flat.numel(), dtype=torch.bfloat16, device=self._flat.device)
             self._wcopy_version = None
@@ -119,7 +126,7 @@ class _TaggerBase(FlatModule):
 
     def mark_weights_synced(self):
         """The fused optimizer wrote the bf16 mirror itself: skip the next cast."""
-        self._wcopy_version = self._flat._version
+        self._wcopy_version = self._weights_version()
 
     def _w(self, wflat, name):
         return self._layout.view(wflat, name)

@@ -460,8 +460,146 @@ def g12_loader():
     save('g12_loader', **out)
 
 
+def g13_inference_collater():
+    """``AudioPortionDatasetInference.collater`` (EncoderDataset.py:198-232): no targets; truncate=True reports every length as
+    truncate_value (:221-222)."""
+    rng = np.random.default_rng(1313)
+    lens = [9, 2, 14, 1, 6]
+    D = 5
+    embs = [torch.from_numpy(rng.standard_normal((n, D)).astype(np.float32)) for n in lens]
+    out = {'lens': np.array(lens, dtype=np.int64)}
+    for i, e in enumerate(embs):
+        out[f'emb{i}'] = e.numpy()
+    for trunc, tv in ((False, 100), (True, 4), (True, 20)):
+        ds = EncoderDataset.AudioPortionDatasetInference(embs, truncate=trunc, truncate_value=tv)
+        batch = ds.collater([ds[i] for i in range(len(ds))])
+        key = f'tr{int(trunc)}_{tv}.'
+        assert sorted(batch.keys()) == ['id', 'src_lengths', 'src_tokens'], batch.keys()
+        out[key + 'src_tokens'] = batch['src_tokens'].numpy()
+        out[key + 'src_lengths'] = batch['src_lengths'].numpy()
+        out[key + 'id'] = batch['id'].numpy()
+    ds = EncoderDataset.AudioPortionDatasetInference(embs)
+    out['empty_is_dict'] = np.array(int(ds.collater([]) == {}))
+    save('g13_inference_collater', **out)
+
+
+def config0_corpus(names, seed=1414, D=768, lo=12, hi=60):
+    """Synthetic stand-in for the NonNews-SBBC corpus (the Zenodo data is not in the tree): one [n_sent, 768] fp32 matrix per file
+    name of NonNews-SBBC/NonNews_split.json, labels ~ Bernoulli(0.2).  Seed recipe shared with tests/ (the matrices are
+    regenerated there, not stored)."""
+    docs = {}
+    for name in names:
+        rng = np.random.default_rng((zlib.crc32(name.encode()) + seed) & 0xFFFFFFFF)
+        n = int(rng.integers(lo, hi))
+        emb = rng.standard_normal((n, D)).astype(np.float32)
+        lab = (rng.random(n) < 0.2).astype(int).tolist()
+        docs[name] = (emb, lab)
+    return docs
+
+
+def g14_config0():
+    """BASELINE.json configs[0]: the reference's own CPU plumbing run -- BiLSTM tagger (H=256, 2 layers, focal loss, Adam lr 1e-3,
+    run_nonnews_unimodal.sh) on precomputed 768-d text-only embeddings, NonNews-SBBC standard split (37/9/8), batch 8:
+    load_dataset_from_precomputed -> AudioPortionDataset.collater -> TextSegmenter.training_step / validation_step / model().
+    Records the split's file names, per-document lengths and labels, the order the loader returns documents in, the loss of every
+    training step of one epoch, the validation losses after it and the boundaries predicted for the test documents."""
+    import json
+    import pickle
+    import tempfile
+    from torch.utils.data import DataLoader
+    from utils.load_datasets_precomputed import load_dataset_from_precomputed
+    with open(os.path.join(REF, 'NonNews-SBBC', 'NonNews_split.json')) as f:
+        split = json.load(f)
+    names = split['train'] + split['validation'] + split['test']
+    docs = config0_corpus(names)
+    out = {'split.train': np.array(split['train']), 'split.validation': np.array(split['validation']),
+           'split.test': np.array(split['test']), 'cfg': np.array([768, 256, 2, 8], dtype=np.int64), 'seed': np.array(1414)}
+    for n in names:
+        out[f'len.{n}'] = np.array(docs[n][0].shape[0])
+        out[f'lab.{n}'] = np.array(docs[n][1], dtype=np.int64)
+        out[f'embsum.{n}'] = checksum(docs[n][0])
+    with tempfile.TemporaryDirectory() as tmp:
+        d = os.path.join(tmp, 'roberta')
+        os.makedirs(d)
+        for n in names:
+            np.save(os.path.join(d, n), docs[n][0])
+        lab_file, split_file = os.path.join(tmp, 'labs_dict.pkl'), os.path.join(tmp, 'split.json')
+        with open(lab_file, 'wb') as f:
+            pickle.dump({n[:-4]: list(docs[n][1]) for n in names}, f)
+        with open(split_file, 'w') as f:
+            json.dump(split, f)
+        folds = load_dataset_from_precomputed(d, lab_file, split=split_file)
+    train, test, valid = folds[0]
+    out['order.train'], out['order.test'], out['order.validation'] = (np.array([it[2] for it in part]) for part in (train, test, valid))
+    tag_to_ix = {'0': 0, '1': 1}
+    mk = lambda part: EncoderDataset.AudioPortionDataset(part, tag_to_ix, encoder='roberta', CRF=False, truncate=False, truncate_value=100)
+    tr_ds, va_ds, te_ds = mk(train), mk(valid), mk(test)
+    bs = 8
+    tr = DataLoader(tr_ds, batch_size=min(bs, len(tr_ds)), collate_fn=tr_ds.collater)          # train_fit.py:141
+    va = DataLoader(va_ds, batch_size=min(bs, len(va_ds)), collate_fn=va_ds.collater)
+    te = DataLoader(te_ds, batch_size=1, collate_fn=te_ds.collater)                              # train_fit.py:154
+    torch.manual_seed(14)
+    ts = TextSegmenter(2, 768, 256, num_layers=2, architecture='BiLSTM', loss_fn='FocalLoss', lr=1e-3, optimizer='Adam',
+                       threshold=0.4)
+    ts.model.device = 'cpu'
+    reseed_model(ts.model, 1414)
+    opt = ts.configure_optimizers()['optimizer']
+    losses = []
+    for bi, batch in enumerate(tr):
+        opt.zero_grad()
+        loss = ts.training_step(batch, bi)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    out['train_losses'] = np.array(losses, dtype=np.float64)
+    with torch.no_grad():
+        out['val_losses'] = np.array([ts.validation_step(b, i).item() for i, b in enumerate(va)], dtype=np.float64)
+        tags, scores = [], []
+        ts.model.th = 0.4
+        for b in te:
+            sc, tg = ts.model(b['src_tokens'], b['src_lengths'])
+            tags.append(np.array(tg[0], dtype=np.int64))
+            scores.append(sc[0, :, 0].numpy().copy())
+    out['test_tags'] = np.concatenate(tags)
+    out['test_scores'] = np.concatenate(scores)
+    save('g14_config0_plumbing', **out)
+
+
+def g15_adjacent_encoders():
+    """SURVEY.md §8(f4) evidence: what the reference itself does when its adjacent-encoder options are selected on a tagger call
+    (GRU: NeuralArchitectures.py:46-50,118-121; unidirectional: :134-145; cosine auxiliary loss: lightning_model.py:276-277;
+    BiLSTMRestrictedMHA: CRF.py:636-684 needs models/longformer_noffn.py, which the reference tree does not contain).
+    Stored: exception type and message per option (empty type = the call succeeded)."""
+    x = torch.randn(3, 7, 16, generator=torch.Generator().manual_seed(15))
+    l = torch.tensor([7, 4, 2])
+    y = (torch.rand(3, 7, generator=torch.Generator().manual_seed(16)) < .3).float()
+    out = {}
+
+    def record(tag, fn):
+        try:
+            fn()
+            out[tag + '.type'], out[tag + '.msg'] = np.array(''), np.array('')
+        except Exception as e:  # noqa: BLE001
+            out[tag + '.type'], out[tag + '.msg'] = np.array(type(e).__name__), np.array(str(e)[:200])
+        print(tag, out[tag + '.type'], out[tag + '.msg'])
+
+    def tagger(**kw):
+        ts = TextSegmenter(2, 16, 8, num_layers=1, architecture='BiLSTM', loss_fn='FocalLoss', **kw)
+        ts.model.device = 'cpu'
+        return ts
+
+    record('gru.loss', lambda: tagger(LSTM=False).model.loss(x, l, y))
+    record('gru.forward', lambda: tagger(LSTM=False).model(x, l))
+    record('unidirectional.loss', lambda: tagger(bidirectional=False).model.loss(x, l, y))
+    record('unidirectional.forward', lambda: tagger(bidirectional=False).model(x, l))
+    record('cosine.training_step', lambda: tagger(cosine_loss=True).training_step({'src_tokens': x, 'tgt_tokens': y, 'src_lengths': l}, 0))
+    out['longformer_noffn_source_present'] = np.array(int(os.path.exists(os.path.join(REF, 'models', 'longformer_noffn.py'))))
+    record('restricted_mha.ctor', lambda: TextSegmenter(2, 16, 8, num_layers=1, architecture='BiLSTMRestrictedMHA', loss_fn='FocalLoss'))
+    save('g15_adjacent_encoders', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g7', 'g3a', 'g3b', 'g3c', 'g2', 'g4', 'g5', 'g6', 'g8', 'g9', 'g10', 'g11', 'g12']
+    which = sys.argv[1:] or ['g1', 'g7', 'g3a', 'g3b', 'g3c', 'g2', 'g4', 'g5', 'g6', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15']
     for w in which:
         if w == 'g1':
             g1_bilstm()
@@ -491,3 +629,9 @@ if __name__ == '__main__':
             g10_legacy()
         elif w == 'g11':
             g11_boundaries()
+        elif w == 'g13':
+            g13_inference_collater()
+        elif w == 'g14':
+            g14_config0()
+        elif w == 'g15':
+            g15_adjacent_encoders()

@@ -1,0 +1,119 @@
+"""Host-side pieces of the PRODUCT (not the oracle) against the fixtures recorded from the reference -- no GPU needed:
+collaters (g8, g13), segment masses (g11), the Keras-style LSTM init (g9 criteria) and the adjacent-encoder options the
+reference itself cannot run (g15)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+
+
+# ------------------------------------------------------------------------------------------------ a1: collaters
+def test_product_collater_matches_reference_fixture():
+    """AudioPortionDataset.collater (EncoderDataset.py:91-152): every field of every configuration of g8, bit for bit."""
+    from multimodaltopicsegmentation_amd import AudioPortionDataset
+    g = H.load('g8_collater')
+    lens = g['lens'].tolist()
+    lines = [(torch.from_numpy(g[f'emb{i}']), g[f'tgt{i}'].tolist(), f'doc{n}') for i, n in enumerate(lens)]
+    lines2 = [(torch.from_numpy(g[f'emb2_{i}']), None, f'doc{n}') for i, n in enumerate(lens)]
+    for crf in (True, False):
+        for trunc, tv in ((False, 100), (True, 5), (True, 16)):
+            ds = AudioPortionDataset(lines, {'0': 0, '1': 1}, CRF=crf, truncate=trunc, truncate_value=tv, second_input=lines2)
+            b = ds.collater([ds[i] for i in range(len(ds))])
+            key = f'crf{int(crf)}_tr{int(trunc)}_{tv}.'
+            assert sorted(b.keys()) == ['domain', 'id', 'src_lengths', 'src_tokens', 'src_tokens2', 'tgt_tokens']
+            assert b['domain'] is None
+            for f in ('src_tokens', 'src_tokens2', 'tgt_tokens', 'src_lengths', 'id'):
+                got = b[f].numpy()
+                assert got.shape == g[key + f].shape and got.dtype == g[key + f].dtype, (key, f, got.dtype, g[key + f].dtype)
+                np.testing.assert_array_equal(got, g[key + f], err_msg=key + f)
+    assert ds.collater([]) == {}
+
+
+def test_product_inference_collater_matches_reference_fixture():
+    """AudioPortionDatasetInference.collater (EncoderDataset.py:198-232), incl. the truncate quirk: lengths = truncate_value."""
+    from multimodaltopicsegmentation_amd import AudioPortionDatasetInference
+    g = H.load('g13_inference_collater')
+    embs = [torch.from_numpy(g[f'emb{i}']) for i in range(len(g['lens']))]
+    for trunc, tv in ((False, 100), (True, 4), (True, 20)):
+        ds = AudioPortionDatasetInference(embs, truncate=trunc, truncate_value=tv)
+        b = ds.collater([ds[i] for i in range(len(ds))])
+        key = f'tr{int(trunc)}_{tv}.'
+        assert sorted(b.keys()) == ['id', 'src_lengths', 'src_tokens']
+        for f in ('src_tokens', 'src_lengths', 'id'):
+            got = b[f].numpy()
+            assert got.shape == g[key + f].shape and got.dtype == g[key + f].dtype, (key, f)
+            np.testing.assert_array_equal(got, g[key + f], err_msg=key + f)
+    assert int(g['empty_is_dict']) == 1 and ds.collater([]) == {}
+
+
+# ------------------------------------------------------------------------------------------------ f1: segment masses
+def test_product_get_boundaries_matches_reference_fixture():
+    from multimodaltopicsegmentation_amd import metrics
+    g = H.load('g11_boundaries')
+    for i in range(6):
+        assert metrics.get_boundaries(g[f'b{i}'].tolist()) == g[f'm{i}'].tolist()
+
+
+# ------------------------------------------------------------------------------------------------ a5: RNN._reinitialize
+@pytest.mark.parametrize('arch', ['BiLSTM', 'BiLSTMLateFusion', 'biLSTMCRF'])
+@pytest.mark.parametrize('hidden', [32, 25])
+def test_product_lstm_init_meets_the_reference_criteria(arch, hidden):
+    """NeuralArchitectures.py:58-79: xavier_uniform W_ih (|w| <= sqrt(6/(fan_in+fan_out)), std ~ bound/sqrt(3)), orthogonal W_hh
+    (columns orthonormal), biases 0 except bias_ih[H:2H] = 1 -- the same criteria g9 records for the reference's own init
+    (tests/test_oracle_vs_golden.py::test_lstm_init_statistics_fixture), asked of the product's reference-shaped state_dict."""
+    from multimodaltopicsegmentation_amd import TextSegmenter
+    g = H.load('g9_lstm_init')
+    torch.manual_seed(9)
+    emb = [48, 40] if arch == 'BiLSTMLateFusion' else 48
+    ts = TextSegmenter(2, emb, hidden, num_layers=2, architecture=arch, loss_fn='FocalLoss')
+    sd = ts.state_dict()
+    seen = 0
+    for k, v in sd.items():
+        a = v.numpy()
+        if 'weight_hh' in k:
+            assert a.shape == (4 * hidden, hidden)
+            assert np.abs(a.T @ a - np.eye(hidden)).max() < 1e-5, k             # same bar as the fixture's 'orth.' entries
+            seen += 1
+        elif 'weight_ih' in k:
+            bound = np.sqrt(6.0 / (a.shape[0] + a.shape[1]))
+            assert np.abs(a).max() <= bound + 1e-6, k
+            assert abs(a.std() / (bound / np.sqrt(3.0)) - 1.0) < 0.05, k          # uniform(-b, b): std = b / sqrt(3)
+            seen += 1
+        elif 'bias_ih' in k:
+            n = a.shape[0]
+            assert np.all(a[n // 4:n // 2] == 1) and np.all(a[:n // 4] == 0) and np.all(a[n // 2:] == 0), k
+            seen += 1
+        elif 'bias_hh' in k:
+            assert np.all(a == 0), k
+            seen += 1
+    nrnn = 2 if arch == 'BiLSTMLateFusion' else 1
+    assert seen == nrnn * 2 * 2 * 4
+    # the fixture's own statistics: the reference's W_ih spread relative to its bound is what the product's must look like
+    ref_ratio = [v[2] / v[1] for k, v in g.items() if k.startswith('xavier.')]
+    assert all(abs(r * np.sqrt(3.0) - 1.0) < 0.05 for r in ref_ratio)
+
+
+# ------------------------------------------------------------------------------------------------ f4: dead upstream, pinned
+def test_adjacent_encoder_options_are_dead_in_the_reference_and_rejected_here():
+    """SURVEY.md §8(f4).  g15 records what the reference does with LSTM=False, bidirectional=False, cosine_loss=True and
+    'BiLSTMRestrictedMHA' on a tagger call: every one of them raises before producing a number (GRU gets an (h0, c0) tuple,
+    the unidirectional path hands a PackedSequence to nn.Linear, no collater emits 'src_segments', longformer_noffn.py is not in
+    the tree).  There is nothing to be in parity with; the product rejects the first two at construction (naming the reason),
+    mirrors the KeyError of the third, and lists the fourth as outside the hot path."""
+    from multimodaltopicsegmentation_amd import TextSegmenter
+    g = H.load('g15_adjacent_encoders')
+    assert str(g['gru.loss.type']) == 'AttributeError' and str(g['gru.forward.type']) == 'AttributeError'
+    assert str(g['unidirectional.loss.type']) == 'TypeError' and str(g['unidirectional.forward.type']) == 'TypeError'
+    assert 'PackedSequence' in str(g['unidirectional.loss.msg'])
+    assert str(g['cosine.training_step.type']) == 'KeyError' and 'src_segments' in str(g['cosine.training_step.msg'])
+    assert int(g['longformer_noffn_source_present']) == 0 and str(g['restricted_mha.ctor.type']) != ''
+    with pytest.raises(NotImplementedError, match='GRU'):
+        TextSegmenter(2, 16, 8, architecture='BiLSTM', loss_fn='FocalLoss', LSTM=False)
+    with pytest.raises(NotImplementedError, match='unidirectional'):
+        TextSegmenter(2, 16, 8, architecture='BiLSTM', loss_fn='FocalLoss', bidirectional=False)
+    with pytest.raises(NotImplementedError):
+        TextSegmenter(2, 16, 8, architecture='BiLSTMRestrictedMHA', loss_fn='FocalLoss')
+    ts = TextSegmenter(2, 16, 8, architecture='BiLSTM', loss_fn='FocalLoss', cosine_loss=True)
+    with pytest.raises(KeyError, match='src_segments'):                            # lightning_model.py:276-277, same as upstream
+        ts.training_step({'src_tokens': torch.zeros(1, 3, 16), 'tgt_tokens': torch.zeros(1, 3), 'src_lengths': torch.tensor([3])}, 0)
