@@ -33,7 +33,8 @@ typedef enum {
   MTS_ERR_INVALID = 1,      /* bad argument (shape, alignment, enum) */
   MTS_ERR_UNSUPPORTED = 2,  /* valid but outside what the kernels cover */
   MTS_ERR_LAUNCH = 3,       /* HIP runtime error at launch */
-  MTS_ERR_WORKSPACE = 4     /* workspace too small */
+  MTS_ERR_WORKSPACE = 4,    /* workspace too small */
+  MTS_ERR_TIMEOUT = 5       /* an EARLIER launch reported a device-side timeout (see mts_async_status): its results are invalid */
 } mts_status;
 
 typedef enum { MTS_F32 = 0, MTS_BF16 = 1 } mts_dtype;
@@ -55,6 +56,8 @@ typedef enum { MTS_NT = 0, MTS_NN = 1, MTS_TN = 2, MTS_TT = 3 } mts_gemm_layout;
 #define MTS_EPI_GELU      4u   /* C = gelu_erf(acc); pre-activation stored to `aux` if non-null */
 #define MTS_EPI_COLSCALE  8u   /* columns n < ncols_scaled are multiplied by colscale (q / sqrt(hd)) */
 #define MTS_EPI_ACCUM    16u   /* C += result (fp32 C only) */
+#define MTS_EPI_RELU     32u   /* C = max(acc, 0); pre-activation stored to `aux` if non-null (legacy layer's FFN,
+                                * models/RestrictedTransformerLayer.py:308); exclusive with MTS_EPI_GELU */
 
 const char* mts_last_error(void);
 /* version / build info: "mts-hip <n> gfx950" */
@@ -62,8 +65,14 @@ const char* mts_version(void);
 /* tuning / A-B switches: "gemm_tile" = 0 (cost model) | 128 | 224 | 256 ; "gemm_glds" = 1 (LDS-DMA staging) | 0 (register
  * staging) ; "gemm_splits" = 0 (cost model) | n ; "gemm_order" = 1 (L2-blocked tile order) | 0 ; "gemm_chain" = 0 | 1 (split-K
  * of the 128x128 kernel accumulates in place) ; "gemm_deep" = 1 (four-buffer copy pipeline of the 128x128 kernel for grids of at
- * most one workgroup per CU) | 0 ; "band_mfma" = 1 | 0 */
+ * most one workgroup per CU) | 0 ; "band_mfma" = 1 | 0 ; "lstm_pair_spin_limit" = re-polls before a CU-pair LSTM workgroup gives
+ * up on its partner (-1 = default 2^22; tests use 0) ; "lstm_pair_max_pairs" = CU pairs per recurrence launch (1..64, default 64) */
 int mts_set_option(const char* key, int value);
+/* Device-side errors that cannot be known at launch time, polled WITHOUT synchronising (a pinned host word the kernels write
+ * with a system-scope store): 0, or MTS_ERR_TIMEOUT when a CU-pair LSTM launch gave up waiting for its partner workgroup since the
+ * last poll (mts_last_error() says which).  mts_lstm_fwd / mts_lstm_bwd poll first themselves, so a training loop sees the error
+ * at the next step at the latest; a host that has synchronised (decode, checkpoint) calls this.  Reading clears. */
+int mts_async_status(void);
 /* tile width (128 | 224 | 256) and K split the cost model chose for the most recent bf16 mts_gemm (bench / profiling labels) */
 int mts_gemm_last_plan(int* tile, int* splits);
 
@@ -131,6 +140,8 @@ int mts_dropout_bwd(void* stream, int dtype, size_t n, const void* dy, void* dx,
 
 /* dy *= gelu_erf'(u) in place (FFN backward; modeling_longformer.py:1113-1116); n elements, n % 4 == 0 */
 int mts_gelu_bwd(void* stream, int dtype, size_t n, const void* u, void* dy);
+/* dy *= (u > 0) in place (backward of the legacy layer's ReLU, models/RestrictedTransformerLayer.py:308); n % 4 == 0 */
+int mts_relu_bwd(void* stream, int dtype, size_t n, const void* u, void* dy);
 
 /* ---------------------------------------------------------------------------------------------
  * PACKED BATCHES (training path; the reference pads every Transformer batch to 3600 sentences, train_fit.py:104-106,

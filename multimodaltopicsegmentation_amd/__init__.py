@@ -8,7 +8,7 @@ from .encoder_dataset import AudioPortionDataset, AudioPortionDatasetInference  
 from .datasets import load_dataset_for_inference, load_dataset_from_precomputed  # noqa: F401
 from .lightning_model import TextSegmenter  # noqa: F401
 from .rnn_taggers import BiLSTM, BiLSTMLateFusion, BiRnnCrf  # noqa: F401
-from .taggers import Transformer_segmenter  # noqa: F401
+from .taggers import RestrictedTransformerEncoderLayer, Transformer_segmenter  # noqa: F401
 
 __all__ = ['TextSegmenter', 'Transformer_segmenter', 'BiLSTM', 'BiLSTMLateFusion', 'BiRnnCrf', 'AudioPortionDataset',
-           'AudioPortionDatasetInference']
+           'AudioPortionDatasetInference', 'RestrictedTransformerEncoderLayer']

@@ -22,7 +22,7 @@ lib = C.CDLL(LIB_PATH)
 F32, BF16 = 0, 1
 LOSS_CE, LOSS_BCE, LOSS_FOCAL = 0, 1, 2
 NT, NN, TN, TT = 0, 1, 2, 3
-EPI_BIAS, EPI_RESIDUAL, EPI_GELU, EPI_COLSCALE, EPI_ACCUM = 1, 2, 4, 8, 16
+EPI_BIAS, EPI_RESIDUAL, EPI_GELU, EPI_COLSCALE, EPI_ACCUM, EPI_RELU = 1, 2, 4, 8, 16, 32
 
 _vp, _i, _f, _u, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint, C.c_size_t
 
@@ -32,6 +32,7 @@ SIGNATURES = {
     'mts_version': (C.c_char_p, []),
     'mts_set_option': (_i, [C.c_char_p, _i]),
     'mts_gemm_last_plan': (_i, [_vp, _vp]),
+    'mts_async_status': (_i, []),
     'mts_gemm': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _u, _f, _i, _vp, _sz]),
     'mts_colsum_workspace': (_sz, [_i]),
     'mts_colsum': (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
@@ -44,6 +45,7 @@ SIGNATURES = {
     'mts_dropout_fwd': (_i, [_vp, _i, _sz, _vp, _vp, _vp, _vp, _f, C.c_uint64]),
     'mts_dropout_bwd': (_i, [_vp, _i, _sz, _vp, _vp, _vp, _f]),
     'mts_gelu_bwd': (_i, [_vp, _i, _sz, _vp, _vp]),
+    'mts_relu_bwd': (_i, [_vp, _i, _sz, _vp, _vp]),
     'mts_band_slots': (_i, [_i]),
     'mts_band_attn_fwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, C.c_uint64]),
     'mts_band_attn_bwd_workspace': (_sz, [_i, _i, _i]),
@@ -88,7 +90,14 @@ def check(rc):
             raise ValueError(msg)                       # MTS_ERR_INVALID  <-> the reference's ValueError / asserts
         if rc == 2:
             raise NotImplementedError(msg)              # MTS_ERR_UNSUPPORTED
+        if rc == 5:
+            raise MtsError(f'device-side timeout: {msg}')   # MTS_ERR_TIMEOUT (reported by the call AFTER the one that failed)
         raise MtsError(f'mts error {rc}: {msg}')
+
+
+def check_async():
+    """Raise if a launch since the last poll reported a device-side error (no synchronisation; see mts_async_status)."""
+    check(lib.mts_async_status())
 
 
 def stream_ptr():

@@ -524,6 +524,8 @@ extern "C" int mts_gemm_last_plan(int* tile, int* splits) {
 }
 
 void mts_band_set_mfma(int on);   // band_attn.hip
+void mts_lstm_pair_set_spin_limit(int n);   // lstm_pair.hip
+void mts_lstm_pair_set_max_pairs(int n);
 extern "C" int mts_set_option(const char* key, int value) {
   if (!key) return MTS_ERR_INVALID;
   if (!strcmp(key, "gemm_tile")) { g_tile_mode = value; return MTS_OK; }
@@ -533,6 +535,8 @@ extern "C" int mts_set_option(const char* key, int value) {
   if (!strcmp(key, "gemm_chain")) { g_chain = value; return MTS_OK; }
   if (!strcmp(key, "gemm_deep")) { g_gemm_deep = value; return MTS_OK; }
   if (!strcmp(key, "band_mfma")) { mts_band_set_mfma(value); return MTS_OK; }
+  if (!strcmp(key, "lstm_pair_spin_limit")) { mts_lstm_pair_set_spin_limit(value); return MTS_OK; }
+  if (!strcmp(key, "lstm_pair_max_pairs")) { mts_lstm_pair_set_max_pairs(value); return MTS_OK; }
   mts_set_error("mts_set_option: unknown key %s", key);
   return MTS_ERR_INVALID;
 }
@@ -575,6 +579,7 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
   MTS_CHECK_ARG(!(epilogue & MTS_EPI_BIAS) || bias, "mts_gemm: MTS_EPI_BIAS without bias");
   MTS_CHECK_ARG(!(epilogue & MTS_EPI_RESIDUAL) || residual, "mts_gemm: MTS_EPI_RESIDUAL without residual");
   MTS_CHECK_ARG(!(epilogue & MTS_EPI_ACCUM) || c_dtype == MTS_F32, "mts_gemm: MTS_EPI_ACCUM needs fp32 C");
+  MTS_CHECK_ARG((epilogue & (MTS_EPI_GELU | MTS_EPI_RELU)) != (MTS_EPI_GELU | MTS_EPI_RELU), "mts_gemm: MTS_EPI_GELU and MTS_EPI_RELU are exclusive");
   hipStream_t st = (hipStream_t)stream;
   GemmArgs a;
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.residual = residual; a.aux = aux;

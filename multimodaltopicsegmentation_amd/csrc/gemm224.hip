@@ -79,7 +79,7 @@ __device__ __forceinline__ void store_tile_224(const GemmArgs& a, f32x4 (&acc)[4
           float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
           if (m < a.M && n < a.N) {
             // same order as epi_math4: bias, column scale, residual, GELU (GELU never comes with a residual in this model)
-            if (has_res && !(a.epi & MTS_EPI_GELU)) {
+            if (has_res && !(a.epi & MTS_EPI_ACT)) {
               epi_math4<bf16_t>(a2, m, n, v, first_slice);
               v[0] += bf16_lo(rr[i][j].x); v[1] += bf16_hi(rr[i][j].x); v[2] += bf16_lo(rr[i][j].y); v[3] += bf16_hi(rr[i][j].y);
             } else {

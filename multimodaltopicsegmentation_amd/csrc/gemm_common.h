@@ -21,6 +21,10 @@ struct GemmArgs {
   float* slab;     // split-K: slice z stores its fp32 partial tile to slab[z][M][N] (plain stores); reduced afterwards
 };
 
+// activation of the epilogue: erf-GELU (HF intermediate layer) or ReLU (legacy RestrictedTransformerEncoderLayer)
+#define MTS_EPI_ACT (MTS_EPI_GELU | MTS_EPI_RELU)
+__device__ __forceinline__ float epi_act(unsigned epi, float x) { return (epi & MTS_EPI_RELU) ? fmaxf(x, 0.0f) : gelu_erf_f(x); }
+
 // ------------------------------------------------------------------------------------------------
 // shared epilogue: lane owns C[m][n..n+3]
 // ------------------------------------------------------------------------------------------------
@@ -42,10 +46,10 @@ __device__ __forceinline__ void epi_math4(const GemmArgs& a, int m, int n, float
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] += r[i];
   }
-  if (epi & MTS_EPI_GELU) {
+  if (epi & MTS_EPI_ACT) {
     if (a.aux) store4<TA>(reinterpret_cast<TA*>(a.aux) + (size_t)m * a.ldaux + n, v);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = gelu_erf_f(v[i]);
+    for (int i = 0; i < 4; ++i) v[i] = epi_act(epi, v[i]);
   }
 }
 
@@ -65,14 +69,14 @@ __device__ __forceinline__ void epi_math8(const GemmArgs& a, int m, int n, float
     v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
     v[4] += bf16_lo(r.z); v[5] += bf16_hi(r.z); v[6] += bf16_lo(r.w); v[7] += bf16_hi(r.w);
   }
-  if (epi & MTS_EPI_GELU) {
+  if (epi & MTS_EPI_ACT) {
     if (a.aux) {
       uint4 pk;
       pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
       *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.aux) + (size_t)m * a.ldaux + n) = pk;
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = gelu_erf_f(v[i]);
+    for (int i = 0; i < 8; ++i) v[i] = epi_act(epi, v[i]);
   }
 }
 
@@ -96,10 +100,10 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, int m, int n, float
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] += r[i];
     }
-    if (epi & MTS_EPI_GELU) {
+    if (epi & MTS_EPI_ACT) {
       if (a.aux) store4<TA>(reinterpret_cast<TA*>(a.aux) + (size_t)m * a.ldaux + n, v);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = gelu_erf_f(v[i]);
+      for (int i = 0; i < 4; ++i) v[i] = epi_act(epi, v[i]);
     }
     TC* c = reinterpret_cast<TC*>(a.C) + (size_t)m * a.ldc + n;
     if constexpr (sizeof(TC) == 4) {
@@ -124,9 +128,9 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, int m, int n, float
       if ((epi & MTS_EPI_BIAS) && first_slice) x += a.bias[n + i];
       if ((epi & MTS_EPI_COLSCALE) && n + i < a.ncols_scaled) x *= a.colscale;
       if ((epi & MTS_EPI_RESIDUAL) && first_slice) x += to_f32(reinterpret_cast<const TA*>(a.residual)[(size_t)m * a.ldr + n + i]);
-      if (epi & MTS_EPI_GELU) {
+      if (epi & MTS_EPI_ACT) {
         if (a.aux) reinterpret_cast<TA*>(a.aux)[(size_t)m * a.ldaux + n + i] = from_f32<TA>(x);
-        x = gelu_erf_f(x);
+        x = epi_act(epi, x);
       }
       TC* c = reinterpret_cast<TC*>(a.C) + (size_t)m * a.ldc + n + i;
       if constexpr (sizeof(TC) == 4) {

@@ -220,7 +220,20 @@ int mts_lstm_pair_fwd(hipStream_t st, int B, int L, int H, int ndir, const void*
                       const int32_t* lengths, void* out, void* gates, float* cells, void* ws);
 int mts_lstm_pair_bwd(hipStream_t st, int B, int L, int H, int ndir, const float* w_hh, const int32_t* lengths, const void* out, const void* gates,
                       const float* cells, const void* dout, void* dxproj, void* hprev, void* ws);
+unsigned mts_lstm_pair_take_error();                  // lstm_pair.hip: sticky timeout word (pinned host memory), reading clears
 static int g_lstm_mfma = 1;
+
+// Asynchronous device-side errors, reported without synchronising: today the only source is a CU-pair LSTM launch whose partner
+// poll gave up.  Every mts_lstm_* entry calls this first, so the error surfaces at the next step at the latest.
+static int lstm_report_async(const char* where) {
+  const unsigned v = mts_lstm_pair_take_error();
+  if (!v) return MTS_OK;
+  mts_set_error("%s: an earlier CU-pair LSTM launch (%s%s) timed out waiting for its partner workgroup; the results of that "
+                "launch are invalid", where, (v & 1u) ? "forward" : "", (v & 2u) ? ((v & 1u) ? "+backward" : "backward") : "");
+  return MTS_ERR_TIMEOUT;
+}
+extern "C" int mts_async_status(void) { return lstm_report_async("mts_async_status"); }
+
 extern "C" void mts_lstm_set_mfma(int on) { g_lstm_mfma = on; }
 
 static int lstm_threads(int H) { return ((H + 63) / 64) * 64; }
@@ -248,6 +261,7 @@ extern "C" int mts_lstm_fwd(void* stream, int dtype, int B, int L, int H, int nd
   MTS_CHECK_ARG(xproj && w_hh && out && gates && cells && workspace, "mts_lstm_fwd: null pointer");
   MTS_CHECK_ARG(dtype == MTS_F32 || dtype == MTS_BF16, "mts_lstm_fwd: bad dtype %d", dtype);
   MTS_UNSUPPORTED(H <= 1024, "mts_lstm_fwd: hidden size %d > 1024", H);
+  if (int rc = lstm_report_async("mts_lstm_fwd")) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (g_lstm_mfma && mts_lstm_pair_supported(dtype, H))
     return mts_lstm_pair_fwd(st, B, L, H, ndir, xproj, w_hh, b_hh, lengths, out, gates, cells, workspace);
@@ -271,6 +285,7 @@ extern "C" int mts_lstm_bwd(void* stream, int dtype, int B, int L, int H, int nd
   MTS_CHECK_ARG(w_hh && out && gates && cells && dout && dxproj && dw_hh && workspace, "mts_lstm_bwd: null pointer");
   MTS_CHECK_ARG(dtype == MTS_F32 || dtype == MTS_BF16, "mts_lstm_bwd: bad dtype %d", dtype);
   MTS_UNSUPPORTED(H <= 1024, "mts_lstm_bwd: hidden size %d > 1024", H);
+  if (int rc = lstm_report_async("mts_lstm_bwd")) return rc;
   hipStream_t st = (hipStream_t)stream;
   const size_t hoff = lstm_scratch_bytes(B, H, ndir);
   char* hprev = (char*)workspace + hoff;

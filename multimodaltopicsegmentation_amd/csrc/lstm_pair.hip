@@ -12,11 +12,15 @@
 // latency is covered by the other's compute; at B = 64 that measured SLOWER (9.0 us per step for two groups vs 4.9 us for
 // one: it halves the number of pairs while 97 % of the CUs idle), hence LP_GROUPS = 1.
 //
-// Safety: both workgroups of a pair are co-resident by construction (the grid is a few dozen workgroups at most);
-// every spin is bounded and a timeout sets a status word instead of hanging; the exchange buffer is zeroed by a
-// memset node before every launch; tags count steps within the call.  Placement (pair members 8 block ids apart =
+// Safety: a workgroup needs ~84 KiB (forward) / ~97 KiB (backward) of LDS, i.e. one per CU, and a pair can only make progress
+// with BOTH halves resident.  A launch therefore covers at most LP_MAX_PAIRS = 64 pairs (128 workgroups, 512 documents x 2
+// directions): larger batches run as several launches over consecutive document ranges, so that even two such grids on two HIP
+// streams (late fusion) fit the 256 CUs together and no resident workgroup can wait for one that cannot be scheduled.
+// Every spin is bounded and a timeout is REPORTED (lp_report_timeout -> MTS_ERR_TIMEOUT at the next call); the exchange buffer
+// is zeroed by a memset node before every launch; tags count steps within the call.  Placement (pair members 8 block ids apart =
 // same XCD under round-robin dispatch) is a speed hint only.
 #include <stdlib.h>
+#include <algorithm>
 #include <type_traits>
 #include "common.h"
 
@@ -25,6 +29,14 @@
 #define LP_SPIN_LIMIT (1u << 22)
 
 typedef unsigned long long u64;
+
+// A partner poll that gives up (LP_SPIN_LIMIT re-polls of ~64 cycles each, about 0.1 s) marks the launch in its own status word
+// and in a pinned HOST word (system-scope store): the host reads that word without synchronising at the next mts_lstm_* call /
+// mts_async_status() and reports MTS_ERR_TIMEOUT, so a launch that computed on stale h never passes silently.
+__device__ __forceinline__ void lp_report_timeout(unsigned* status, unsigned* sticky, unsigned bit) {
+  atomicOr(status, bit);
+  __hip_atomic_store(sticky, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // v_rcp_f32 (1 ulp) instead of __frcp_rn: the correctly rounded reciprocal is a ten-instruction division sequence, and the
 // 20 of them per step were a third of the time loop's instruction stream; the results are rounded to bf16 anyway
@@ -59,7 +71,8 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_fwd_pair_kernel(int B, int L,
                                                                    const bf16_t* __restrict__ wpk, const float* __restrict__ bhh,
                                                                    const int32_t* __restrict__ lengths, bf16_t* __restrict__ out,
                                                                    bf16_t* __restrict__ gates, float* __restrict__ cells, u64* __restrict__ xch,
-                                                                   unsigned* __restrict__ status, char* __restrict__ dump, int xflags) {
+                                                                   unsigned* __restrict__ status, char* __restrict__ dump, int xflags,
+                                                                   unsigned spin_limit, unsigned* __restrict__ sticky) {
   constexpr int H = KS * 32;
   constexpr int HH = H / 2;                              // units per workgroup
   constexpr int NT = KS * 64;                            // threads
@@ -177,7 +190,7 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_fwd_pair_kernel(int B, int L,
 #pragma clang loop unroll(disable)
       for (;;) {
         asm volatile("" : "+s"(spins));                 // opaque counter: keeps the compiler from replicating the poll hundreds of times
-        if (++spins > LP_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(status, 1u); break; }
+        if (++spins > spin_limit) { dead = true; if (lane == 0) lp_report_timeout(status, sticky, 1u); break; }
         __builtin_amdgcn_s_sleep(1);
 #pragma unroll
         for (int k = 0; k < GPT; ++k) v[k] = __hip_atomic_load(src + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -311,6 +324,34 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_fwd_pair_kernel(int B, int L,
 
 // ---- host side ---------------------------------------------------------------------------------------
 static int g_pair_mode = -1;   // MTS_LSTM_PAIR=0 disables
+#define LP_MAX_PAIRS 64
+static unsigned g_spin_limit = LP_SPIN_LIMIT;      // mts_set_option("lstm_pair_spin_limit", n): tests force a timeout with n = 0
+static int g_max_pairs = LP_MAX_PAIRS;             // mts_set_option("lstm_pair_max_pairs", n): tests exercise the multi-launch path
+static unsigned* g_sticky_host = nullptr;          // pinned, device-visible: non-zero = some pair launch timed out
+static unsigned* g_sticky_dev = nullptr;
+
+void mts_lstm_pair_set_spin_limit(int n) { g_spin_limit = n < 0 ? LP_SPIN_LIMIT : (unsigned)n; }
+void mts_lstm_pair_set_max_pairs(int n) { g_max_pairs = (n <= 0 || n > LP_MAX_PAIRS) ? LP_MAX_PAIRS : n; }
+
+static int lp_ensure_sticky() {
+  if (g_sticky_dev) return MTS_OK;
+  void* h = nullptr;
+  if (hipHostMalloc(&h, 256, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { mts_set_error("lstm_pair: hipHostMalloc failed"); return MTS_ERR_LAUNCH; }
+  *(volatile unsigned*)h = 0u;
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { mts_set_error("lstm_pair: hipHostGetDevicePointer failed"); return MTS_ERR_LAUNCH; }
+  g_sticky_host = (unsigned*)h;
+  g_sticky_dev = (unsigned*)d;
+  return MTS_OK;
+}
+
+// bit 0: a forward pair launch timed out, bit 1: a backward one; reading clears
+unsigned mts_lstm_pair_take_error() {
+  if (!g_sticky_host) return 0u;
+  const unsigned v = *(volatile unsigned*)g_sticky_host;
+  if (v) *(volatile unsigned*)g_sticky_host = 0u;
+  return v;
+}
 
 bool mts_lstm_pair_supported(int dtype, int H) {
   if (g_pair_mode < 0) { const char* e = getenv("MTS_LSTM_PAIR"); g_pair_mode = (e && e[0] == '0') ? 0 : 1; }
@@ -345,9 +386,18 @@ int mts_lstm_pair_fwd(hipStream_t st, int B, int L, int H, int ndir, const void*
   }
   static int xflags = -1;
   if (xflags < 0) { const char* e = getenv("MTS_LSTM_EXP"); xflags = e ? atoi(e) : 0; }
-  const int npairs = ceil_div(B, LP_DOCS * LP_GROUPS) * ndir;
-  hipLaunchKernelGGL(k, dim3(16 * ceil_div(npairs, 8)), dim3(KS * 64), lds, st, B, L, ndir, npairs, (const bf16_t*)xproj, (const bf16_t*)wpk, b_hh,
-                     lengths, (bf16_t*)out, (bf16_t*)gates, cells, xch, status, (char*)status + 256, xflags);
+  if (int rc = lp_ensure_sticky()) return rc;
+  // at most g_max_pairs pairs per launch (see "Safety" at the top): documents [b0, b0 + bc) per launch, rows are b * L + i
+  const int docs_per_launch = std::max(1, g_max_pairs / ndir) * LP_DOCS * LP_GROUPS;
+  for (int b0 = 0; b0 < B; b0 += docs_per_launch) {
+    const int bc = std::min(docs_per_launch, B - b0);
+    const size_t r0 = (size_t)b0 * L;
+    if (b0 > 0 && hipMemsetAsync(xch, 0, pair_xbytes(bc, ndir) + 256, st) != hipSuccess) { mts_set_error("lstm_pair: memset failed"); return MTS_ERR_LAUNCH; }
+    const int npairs = ceil_div(bc, LP_DOCS * LP_GROUPS) * ndir;
+    hipLaunchKernelGGL(k, dim3(16 * ceil_div(npairs, 8)), dim3(KS * 64), lds, st, bc, L, ndir, npairs, (const bf16_t*)xproj + r0 * ndir * 4 * H,
+                       (const bf16_t*)wpk, b_hh, lengths ? lengths + b0 : nullptr, (bf16_t*)out + r0 * ndir * H, (bf16_t*)gates + r0 * ndir * 4 * H,
+                       cells + r0 * ndir * H, xch, status, (char*)status + 256, xflags, g_spin_limit, g_sticky_dev);
+  }
   MTS_LAUNCH_CHECK("mts_lstm_fwd(pair)");
   return MTS_OK;
 }
@@ -396,7 +446,7 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_bwd_pair_kernel(int B, int L,
                                                                    const int32_t* __restrict__ lengths, const bf16_t* __restrict__ gates,
                                                                    const float* __restrict__ cells, const bf16_t* __restrict__ dout,
                                                                    bf16_t* __restrict__ dxproj, u64* __restrict__ xch, unsigned* __restrict__ status,
-                                                                   char* __restrict__ dump) {
+                                                                   char* __restrict__ dump, unsigned spin_limit, unsigned* __restrict__ sticky) {
   static_assert(LP_GROUPS == 1 && KS == 8, "the backward pair kernel serves one group of documents per pair, H = 256");
   constexpr int H = KS * 32, HH = H / 2, NT = KS * 64;
   constexpr int KT = 4 * HH / 32;                        // k-steps over the 512 own gate columns
@@ -474,7 +524,7 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_bwd_pair_kernel(int B, int L,
 #pragma clang loop unroll(disable)
       for (;;) {
         asm volatile("" : "+s"(spins));                 // opaque counter: keeps the compiler from replicating the poll hundreds of times
-        if (++spins > LP_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(status, 2u); break; }
+        if (++spins > spin_limit) { dead = true; if (lane == 0) lp_report_timeout(status, sticky, 2u); break; }
         __builtin_amdgcn_s_sleep(1);
         fetch_issue(s);
         if (tags_ok()) break;
@@ -606,9 +656,17 @@ int mts_lstm_pair_bwd(hipStream_t st, int B, int L, int H, int ndir, const float
     }
     attr = true;
   }
-  const int npairs = ceil_div(B, LP_DOCS * LP_GROUPS) * ndir;
-  hipLaunchKernelGGL(k, dim3(16 * ceil_div(npairs, 8)), dim3(KS * 64), lds, st, B, L, ndir, npairs, (const bf16_t*)wpk, lengths, (const bf16_t*)gates,
-                     cells, (const bf16_t*)dout, (bf16_t*)dxproj, xch, status, (char*)status + 256);
+  if (int rc = lp_ensure_sticky()) return rc;
+  const int docs_per_launch = std::max(1, g_max_pairs / ndir) * LP_DOCS * LP_GROUPS;
+  for (int b0 = 0; b0 < B; b0 += docs_per_launch) {
+    const int bc = std::min(docs_per_launch, B - b0);
+    const size_t r0 = (size_t)b0 * L;
+    if (b0 > 0 && hipMemsetAsync(xch, 0, pair_xbytes(bc, ndir) + 256, st) != hipSuccess) { mts_set_error("lstm_pair: memset failed"); return MTS_ERR_LAUNCH; }
+    const int npairs = ceil_div(bc, LP_DOCS * LP_GROUPS) * ndir;
+    hipLaunchKernelGGL(k, dim3(16 * ceil_div(npairs, 8)), dim3(KS * 64), lds, st, bc, L, ndir, npairs, (const bf16_t*)wpk, lengths ? lengths + b0 : nullptr,
+                       (const bf16_t*)gates + r0 * ndir * 4 * H, cells + r0 * ndir * H, (const bf16_t*)dout + r0 * ndir * H,
+                       (bf16_t*)dxproj + r0 * ndir * 4 * H, xch, status, (char*)status + 256, g_spin_limit, g_sticky_dev);
+  }
   MTS_LAUNCH_CHECK("mts_lstm_bwd(pair)");
   return MTS_OK;
 }

@@ -767,3 +767,26 @@ extern "C" int mts_gelu_bwd(void* stream, int dtype, size_t n, const void* u, vo
   MTS_LAUNCH_CHECK("mts_gelu_bwd");
   return MTS_OK;
 }
+
+// dy *= (u > 0), in place on dy (backward of the legacy layer's ReLU FFN, models/RestrictedTransformerLayer.py:308)
+template <typename T>
+__global__ __launch_bounds__(256) void relu_bwd_kernel(size_t n, const T* __restrict__ u, T* __restrict__ dy) {
+  const size_t stride = (size_t)gridDim.x * 256 * 4;
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i + 3 < n; i += stride) {
+    float uv[4], dv[4];
+    load4<T>(u + i, uv); load4<T>(dy + i, dv);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dv[j] = uv[j] > 0.0f ? dv[j] : 0.0f;
+    store4<T>(dy + i, dv);
+  }
+}
+extern "C" int mts_relu_bwd(void* stream, int dtype, size_t n, const void* u, void* dy) {
+  MTS_CHECK_ARG(u && dy && n % 4 == 0, "mts_relu_bwd: bad arguments (n must be a multiple of 4)");
+  if (n == 0) return MTS_OK;
+  const int blocks = (int)std::min<size_t>(2048, (n / 4 + 255) / 256);
+  if (dtype == MTS_F32) hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, (const float*)u, (float*)dy);
+  else if (dtype == MTS_BF16) hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, (const bf16_t*)u, (bf16_t*)dy);
+  else { mts_set_error("mts_relu_bwd: bad dtype %d", dtype); return MTS_ERR_INVALID; }
+  MTS_LAUNCH_CHECK("mts_relu_bwd");
+  return MTS_OK;
+}

@@ -64,7 +64,7 @@ _plan_cache = {}
 
 
 def gemm(layout, A, B, out, *, M, N, K, lda=None, ldb=None, ldc=None, bias=None, residual=None, aux=None, gelu=False,
-         colscale=None, ncols_scaled=0, accumulate=False):
+         colscale=None, ncols_scaled=0, accumulate=False, relu=False):
     """C[M,N] = op(A) op(B) (+ epilogue).  A/B share a dtype (fp32 or bf16); out is fp32 or that dtype."""
     a_dt = dtype_code(A.dtype)
     assert B.dtype == A.dtype
@@ -76,6 +76,8 @@ def gemm(layout, A, B, out, *, M, N, K, lda=None, ldb=None, ldc=None, bias=None,
         epi |= L.EPI_RESIDUAL
     if gelu:
         epi |= L.EPI_GELU
+    if relu:
+        epi |= L.EPI_RELU
     if colscale is not None:
         epi |= L.EPI_COLSCALE
     if accumulate:
@@ -167,6 +169,10 @@ def dropout_bwd(dy, dx, mask, p):
 
 def gelu_bwd(u, dy):
     check(lib.mts_gelu_bwd(stream_ptr(), dtype_code(u.dtype), u.numel(), ptr(u), ptr(dy)))
+
+
+def relu_bwd(u, dy):
+    check(lib.mts_relu_bwd(stream_ptr(), dtype_code(u.dtype), u.numel(), ptr(u), ptr(dy)))
 
 
 def band_slots(radius):

