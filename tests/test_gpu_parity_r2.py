@@ -71,7 +71,9 @@ def test_legacy_restricted_layer_on_hip_kernels(dtype):
     p = {k[2:]: torch.from_numpy(v).double().requires_grad_(True) for k, v in g.items() if k.startswith('w.')}
     xr = torch.from_numpy(g['x']).double().requires_grad_(True)
     (R.legacy_restricted_layer(xr, p, h, w) * c.double()).sum().backward()
-    rt, at = (2e-3, 2e-5) if f32 else (0.1, 3e-2)
+    # bf16: ReLU'(u) flips wherever bf16 rounding moves a pre-activation across 0, and at d = 32 one flipped unit is a visible
+    # share of a gradient entry -> 0.2 of each tensor's max (fp32 mode holds 2e-3)
+    rt, at = (2e-3, 2e-5) if f32 else (0.2, 3e-2)
     assert float((xg.grad.cpu().double() - xr.grad).abs().max()) < rt * float(xr.grad.abs().max()) + at
     for n, prm in layer.named_parameters():
         a, r = layer.logical_view({n: prm.grad}, n).detach().cpu().double(), p[n].grad
