@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+PMC_TRAFFIC_FILE = 'r02_pmc_traffic.json'   # written by tools/pmc_traffic.py from two rocprofv3 --pmc passes, stamped with csrc_sha()
 
 
 def fwd_bwd_mflop_per_sentence(D, ff, radius, n_layers, n_out=1):
@@ -53,32 +54,68 @@ def synthetic_batch(B, L, D, rank, device, D2=None, ragged=False):
     return batch
 
 
+def csrc_sha():
+    """Hash of the kernel sources in the tree: ties a measurement artifact (profiles/*_pmc_traffic.json) to the build it was taken
+    on -- .git does not travel to the GPU box, the sources do."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'multimodaltopicsegmentation_amd', 'csrc')
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith(('.hip', '.h')):
+            h.update(fn.encode())
+            h.update(open(os.path.join(d, fn), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(args, D, ff, heads, window, n_layers):
-    """The CPU oracle (a port of the reference's arithmetic, oracle/restatement.py) timed on this box's host cores on a
-    bounded sample of the same workload: fwd + bwd + Adam, fp32."""
+    """The CPU oracle (a port of the reference's arithmetic, oracle/restatement.py, with the block-wise matmul form of the band
+    attention) timed on this box's host cores on a bounded sample of the same workload: fwd + bwd + Adam, fp32.  The thread count
+    is the one that maximises the port's throughput on a short probe (an 8-32 document batch does not scale to 128 threads)."""
     from oracle import restatement as R
     from tests import helpers as H
-    Bc = args.cpu_docs
-    cores = torch.get_num_threads()
-    p = H.seeded_params(H.band_param_shapes(D, ff, n_layers, 1, max_pos=args.seq + 2), 7, torch.float32, True)
-    opt = torch.optim.Adam(list(p.values()), lr=1e-3, eps=1e-7)
-    g = torch.Generator().manual_seed(99)
-    x = torch.randn(Bc, args.seq, D, generator=g)
-    y = (torch.rand(Bc, args.seq, generator=g) < 0.05).float()
-    lengths = torch.full((Bc,), args.seq)
     radii = R.pyramidal_radii(n_layers, window)
-    times = []
-    for it in range(3):
-        t0 = time.perf_counter()
-        opt.zero_grad()
-        loss = R.tagger_loss(R.transformer_scores(x, lengths, p, heads, radii), lengths, y, 'FocalLoss')
-        loss.backward()
-        opt.step()
-        times.append(time.perf_counter() - t0)
-    best = min(times[1:])
-    return {'value': Bc * args.seq / best, 'unit': 'sentences/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{Bc} docs x {args.seq} sentences x {D}-d, same model, fp32 fwd+bwd+Adam, best of 2 after 1 warm-up '
-                      f'({best:.2f} s/step)'}
+    g = torch.Generator().manual_seed(99)
+
+    def make(Bc):
+        p = H.seeded_params(H.band_param_shapes(D, ff, n_layers, 1, max_pos=args.seq + 2), 7, torch.float32, True)
+        opt = torch.optim.Adam(list(p.values()), lr=1e-3, eps=1e-7)
+        x = torch.randn(Bc, args.seq, D, generator=g)
+        y = (torch.rand(Bc, args.seq, generator=g) < 0.05).float()
+        lengths = torch.full((Bc,), args.seq)
+
+        def step():
+            t0 = time.perf_counter()
+            opt.zero_grad()
+            R.tagger_loss(R.transformer_scores(x, lengths, p, heads, radii, attention=R.band_attention_blocked), lengths, y, 'FocalLoss').backward()
+            opt.step()
+            return time.perf_counter() - t0
+        return step
+
+    ncpu = os.cpu_count() or 1
+    probe = make(min(8, args.cpu_docs))
+    probe()                                                    # warm-up (allocator, thread pool)
+    cands = sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu} or {ncpu})
+    timing = {}
+    for t in cands:
+        torch.set_num_threads(t)
+        probe()
+        timing[t] = probe()
+    cores = min(timing, key=timing.get)
+    torch.set_num_threads(cores)
+    step = make(args.cpu_docs)
+    step()
+    best = min(step(), step())
+    sample = (f'{args.cpu_docs} docs x {args.seq} sentences x {D}-d, same model, fp32 fwd+bwd+Adam, best of 2 after 1 warm-up '
+              f'({best:.2f} s/step); threads picked from {cands} by a probe on {min(8, args.cpu_docs)} docs '
+              f'({", ".join(f"{t}: {v:.2f} s" for t, v in timing.items())})')
+    try:
+        rv = json.load(open(os.path.join(ROOT, 'profiles', 'r02_cpu_ref_vs_port.json')))
+        sample += (f'; port vs the reference itself, measured in the build container ({rv["sample"]}, {rv["threads"]} threads, '
+                   f'tools/cpu_ref_vs_port.py): reference {rv["reference_sentences_per_s"]:.0f} sentences/s, this port '
+                   f'{rv["port_blocked_sentences_per_s"]:.0f} = {rv["port_blocked_vs_reference"]:.2f}x the reference')
+    except (OSError, ValueError, KeyError):
+        sample += '; port-vs-reference ratio: profiles/r02_cpu_ref_vs_port.json missing'
+    return {'value': args.cpu_docs * args.seq / best, 'unit': 'sentences/s', 'cores': cores, 'kind': 'port', 'sample': sample}
 
 
 def main():
@@ -92,7 +129,8 @@ def main():
     ap.add_argument('--arch', default='transformer', choices=['transformer', 'bilstm', 'bilstm_crf', 'latefusion'])
     ap.add_argument('--layers', type=int, default=None)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
-    ap.add_argument('--cpu-docs', type=int, default=8)
+    ap.add_argument('--cpu-docs', type=int, default=32)
+    ap.add_argument('--sustained-steps', type=int, default=1000, help='extra timed leg after the K-step region (0 = skip); reported under "extra"')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true')
     ap.add_argument('--ragged', action='store_true', help='ragged lengths U{L/4..L} (value counts valid sentences only)')
@@ -149,6 +187,16 @@ def main():
         model = BiLSTMLateFusion(2, [D, D2], 256, num_layers=n_layers, loss_fn='FocalLoss', compute_dtype=args.dtype, seed=1234)
         mflop = 47.19 if n_layers == 2 else None
         wl = f'late fusion (concat) two BiLSTMs {D}+{D2} H=256 layers={n_layers} focal loss'
+    # which BASELINE.json configuration this run is (per-GPU workload); anything else is labelled as a variant
+    std = args.docs == 64 and args.dim == 1792 and not args.ragged
+    if args.arch == 'transformer' and std and args.seq == 256 and n_layers == 1:
+        cfg_label = 'BASELINE configs[1]' if world == 1 else f'BASELINE configs[3] ({world} of 8 GPUs)' if world < 8 else 'BASELINE configs[3]'
+    elif args.arch in ('bilstm', 'bilstm_crf') and std and args.seq == 256 and n_layers == 2:
+        cfg_label = 'BASELINE configs[2] (' + ('CRF NLL head' if args.arch == 'bilstm_crf' else 'focal-loss head') + ')'
+    elif args.arch == 'latefusion' and args.docs == 64 and args.seq == 512 and n_layers == 2:
+        cfg_label = 'BASELINE configs[4] per-GPU workload' + (f' ({world} GPU{"s" if world > 1 else ""})')
+    else:
+        cfg_label = 'variant (not a BASELINE.json configuration)'
     model = model.to(device)
     trainer = NativeTrainer(model, lr=1e-3, optimizer='Adam')
     batch = synthetic_batch(args.docs, args.seq, D, rank, device, D2, ragged=args.ragged)
@@ -198,6 +246,21 @@ def main():
         t = torch.tensor([elapsed], device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+    # sustained figure: the K-step value above is taken on a chip that has been busy for a fraction of a second; under sustained
+    # load the clock settles lower (DVFS), so the same build is timed again over >= 1000 steps (no per-kernel events)
+    sustained = None
+    if args.sustained_steps > 0:
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.sustained_steps):
+            trainer.step(batch)
+        sync()
+        sus = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([sus], device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sus = float(t)
+        sustained = sus
 
     if rank == 0:
         sentences = world * int(batch['src_lengths'].sum()) * args.steps      # valid sentences (= docs x seq unless --ragged)
@@ -206,11 +269,15 @@ def main():
             'metric': 'sentences/sec (fwd+bwd)', 'value': value, 'unit': 'sentences/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': f'BASELINE configs[1]: {wl}, {args.docs} docs x {args.seq} sentences per GPU, '
+            'config': {'workload': f'{cfg_label}: {wl}, {args.docs} docs x {args.seq} sentences per GPU, '
                                    f'fwd+bwd+Adam(eps 1e-7), inputs resident in HBM' + (', ragged lengths U{L/4..L}' + (' (padded rows kept)' if args.no_pack else ' (packed)') if args.ragged else ''),
                        'global_batch_docs': world * args.docs, 'sentences_per_doc': args.seq, 'parallelism': f'dp{world} (document-sharded, RCCL all-reduce)'},
             'final_loss': loss_val,
         }
+        if sustained is not None:
+            out['extra'] = {'sustained_steps': args.sustained_steps, 'sustained_ms_per_step': 1e3 * sustained / args.sustained_steps,
+                            'sustained_value': world * int(batch['src_lengths'].sum()) * args.sustained_steps / sustained,
+                            'note': 'same build, timed again over sustained_steps right after the K-step region (clock settled under load)'}
         if mflop:
             out['model_tflops'] = value * mflop / 1e6
             out['model_mfma_frac'] = out['model_tflops'] / (MFMA_BF16_PEAK_TFLOPS * world)
@@ -247,16 +314,22 @@ def main():
             key, dom = max(per_sym.items(), key=lambda kv: kv[1]['ms'])
             ach = dom['flop'] / (dom['ms'] * 1e-3) / 1e12
             # HBM-side bytes per launch from the committed PMC passes (profiles/: FETCH_SIZE x2 + WRITE_SIZE, see tools/pmc_traffic.py)
-            traffic = None
+            # the JSON is stamped with the hash of the kernel sources it was measured on; a different build gets traffic = null
+            traffic, traffic_note = None, None
             try:
-                pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')))
-                traffic = sum(pmc[k]['bytes_per_launch'] for k in rocprof_names.get(key, []) if k in pmc) or None
-            except (OSError, ValueError, KeyError):
-                pass
+                pmc = json.load(open(os.path.join(ROOT, 'profiles', PMC_TRAFFIC_FILE)))
+                if pmc.get('_csrc_sha') != csrc_sha():
+                    traffic_note = f'{PMC_TRAFFIC_FILE} was taken on kernel sources {pmc.get("_csrc_sha")}, this build is {csrc_sha()}: not quoted'
+                else:
+                    traffic = sum(pmc[k]['bytes_per_launch'] for k in rocprof_names.get(key, []) if k in pmc) or None
+            except (OSError, ValueError, KeyError) as e:
+                traffic_note = f'{PMC_TRAFFIC_FILE}: {type(e).__name__}'
             out['roofline'] = {'bound': 'mfma', 'kernel': sym.get(key, str(key)), 'achieved': ach, 'peak': MFMA_BF16_PEAK_TFLOPS,
                                'unit': 'TFLOP/s', 'frac': ach / MFMA_BF16_PEAK_TFLOPS, 'traffic': traffic,
                                'launches_timed': dom['launches'], 'avg_launch_us': 1e3 * dom['ms'] / dom['launches'],
                                'algorithmic_gflop_per_launch': dom['flop'] / dom['launches'] / 1e9}
+            if traffic_note:
+                out['roofline']['traffic_note'] = traffic_note
             out['kernels_note'] = 'per-launch averages from the warm-up steps (every GEMM / band launch bracketed by HIP events); the roofline entry and band_attn_fwd are from the timed region'
             out['kernels'] = {sym.get(k, str(k)): {'launches': d['launches'], 'avg_us': 1e3 * d['ms'] / d['launches'],
                                                     'tflops': d['flop'] / (d['ms'] * 1e-3) / 1e12} for k, d in wper_sym.items()}

@@ -249,6 +249,10 @@ int mts_adam_step(void* stream, size_t n, float* param, const float* grad, float
                   float lr, float beta1, float beta2, float eps, int step, float grad_scale, void* bf16_copy);
 int mts_sgd_step(void* stream, size_t n, float* param, const float* grad, float* momentum_buf, float lr,
                  float momentum, float weight_decay, int first_step, float grad_scale, void* bf16_copy);
+/* x[0..n) *= scale (fp32).  Token-weighted data parallelism: the reference's loss is a mean over the LOCAL batch's valid
+ * sentences (models/CRF.py:352); multiplying d loss / d scores by world * n_local / n_global before the SUM all-reduce (and
+ * grad_scale = 1/world in the optimizer) gives the single-process gradient of the global batch. */
+int mts_scale(void* stream, size_t n, float* x, float scale);
 
 #ifdef __cplusplus
 }

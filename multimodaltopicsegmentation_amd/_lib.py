@@ -64,6 +64,7 @@ SIGNATURES = {
     'mts_crf_viterbi': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'mts_adam_step': (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i, _f, _vp]),
     'mts_sgd_step': (_i, [_vp, _sz, _vp, _vp, _vp, _f, _f, _f, _i, _f, _vp]),
+    'mts_scale': (_i, [_vp, _sz, _vp, _f]),
 }
 
 _missing = []

@@ -87,3 +87,18 @@ extern "C" int mts_sgd_step(void* stream, size_t n, float* param, const float* g
   MTS_LAUNCH_CHECK("mts_sgd_step");
   return MTS_OK;
 }
+
+// x *= scale (fp32, any n): the loss-gradient weight of token-weighted data parallelism (trainer.py: a rank's d loss / d scores
+// is multiplied by world * n_r / sum n_r before the SUM all-reduce)
+__global__ __launch_bounds__(256) void scale_kernel(size_t n, float* __restrict__ x, float scale) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) x[i] *= scale;
+}
+extern "C" int mts_scale(void* stream, size_t n, float* x, float scale) {
+  MTS_CHECK_ARG(x || n == 0, "mts_scale: null pointer");
+  if (n == 0 || scale == 1.0f) return MTS_OK;
+  const int blocks = (int)std::min<size_t>(1024, (n + 255) / 256);
+  hipLaunchKernelGGL(scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, x, scale);
+  MTS_LAUNCH_CHECK("mts_scale");
+  return MTS_OK;
+}

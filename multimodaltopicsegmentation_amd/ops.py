@@ -269,3 +269,11 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, gra
 def sgd_step(param, grad, buf, lr, momentum, weight_decay, first_step, grad_scale=1.0, bf16_copy=None):
     check(lib.mts_sgd_step(stream_ptr(), param.numel(), ptr(param), ptr(grad), ptr(buf), lr, momentum, weight_decay,
                            int(first_step), grad_scale, ptr(bf16_copy)))
+
+
+def scale_(x, scale):
+    """x *= scale in place (fp32, contiguous)."""
+    if scale != 1.0:
+        assert x.dtype == torch.float32 and x.is_contiguous()
+        check(lib.mts_scale(stream_ptr(), x.numel(), ptr(x), float(scale)))
+    return x

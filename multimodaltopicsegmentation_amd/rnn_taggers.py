@@ -244,6 +244,7 @@ class BiLSTM(_RnnTaggerBase):
         dsc = self._ws.get('dscores', B * Lq, self.n_out, torch.float32, dev) if want_grad else None
         ops.tagger_loss(self.loss_kind, st['scores'], tg, st['li32'], self.alpha, self.gamma, loss_out, dsc)
         if want_grad:
+            ops.scale_(dsc, self.loss_grad_scale)
             g, lay = self.grad_flat(), self._layout
             ops.head_bwd_params(st['h'], dsc, lay.view(g, 'classification.weight'), lay.view(g, 'classification.bias'))
             self._grads_ready(*self._span_of('classification.weight', 'classification.bias'))
@@ -341,6 +342,7 @@ class BiLSTMLateFusion(_RnnTaggerBase):
         dsc = self._ws.get('dscores', B * Lq, self.n_out, torch.float32, dev) if want_grad else None
         ops.tagger_loss(self.loss_kind, st['scores'], tg, st['li32'], self.alpha, self.gamma, loss_out, dsc)
         if want_grad:
+            ops.scale_(dsc, self.loss_grad_scale)
             g, lay = self.grad_flat(), self._layout
             ops.head_bwd_params(st['cat'], dsc, lay.view(g, 'classification.weight'), lay.view(g, 'classification.bias'))
             self._grads_ready(*self._span_of('classification.weight', 'classification.bias'))
@@ -436,6 +438,8 @@ class BiRnnCrf(_RnnTaggerBase):
         ops.crf_nll(st['feats'], tg, st['li32'], self._w(self._flat, 'crf.transitions'), loss_out,
                     dfe.view(B, Lq, C) if want_grad else None, lay.view(g, 'crf.transitions') if want_grad else None)
         if want_grad:
+            ops.scale_(dfe, self.loss_grad_scale)
+            ops.scale_(lay.view(g, 'crf.transitions'), self.loss_grad_scale)
             ops.head_bwd_params(st['h'], dfe, lay.view(g, 'crf.fc.weight'), lay.view(g, 'crf.fc.bias'))
             self._grads_ready(*self._span_of('crf.fc.weight', 'crf.transitions'))
             dout = self._ws.get('dout', B * Lq, 2 * self._hp, self.compute_dtype, dev)

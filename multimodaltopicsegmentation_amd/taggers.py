@@ -116,6 +116,7 @@ class _TaggerBase(FlatModule):
             self._wcopy_version = ver
         return self._wcopy
 
+    loss_grad_scale = 1.0            # multiplies d loss / d scores (trainer.NativeTrainer: token-weighted data parallelism)
     _grad_hook = None
     grad_hooks_cover_all = False     # subclasses that announce every parameter span through _grads_ready set this
 
@@ -279,8 +280,17 @@ class _TaggerBase(FlatModule):
         dsc = ws.get('dsc', N, H * S['slots'], torch.float32, dev)
         ops.band_attn_bwd(S['qkv'], lengths_i32, S['probs'], dctx, B, Lq, D, H, S['radius'], dqkv, dsc,
                           dbias=Gv('bqkv', 1, 3 * D).view(-1), row0=row0, drop_p=S['pattn'], drop_seed=S['aseed'])
-        wgrad(dqkv, S['hin'], Gv('wqkv', 3 * D, D))
-        self._grads_ready(lay.entries[names['wqkv'][0]][0], o_wo)    # q/k/v weights + biases
+        o_qkv = lay.entries[names['wqkv'][0]][0]
+        if self._grad_hook is not None:
+            # data parallel: one weight-gradient GEMM per projection, each third handed to the exchange as soon as it is final --
+            # what is still in flight when the backward ends is the last 12.8 MB instead of the whole 38.5 MB q/k/v block
+            gq = Gv('wqkv', 3 * D, D)
+            for i in range(3):
+                wgrad(dqkv[:, i * D:(i + 1) * D], S['hin'], gq[i * D:(i + 1) * D])
+                self._grads_ready(o_qkv + i * D * D, o_qkv + (i + 1) * D * D if i < 2 else o_wo)   # the last one carries the biases
+        else:
+            wgrad(dqkv, S['hin'], Gv('wqkv', 3 * D, D))
+            self._grads_ready(o_qkv, o_wo)                         # q/k/v weights + biases
         dhin = ws.get(f'dhin{slot}', N, D, dt, dev)
         ops.linear_dgrad(dqkv, self._lt(wf, names, 'wqkv', 3 * D, D), dhin, residual=ds1)
         return dhin
@@ -577,6 +587,7 @@ class Transformer_segmenter(_TaggerBase):
         ops.tagger_loss(self.loss_kind, st['scores'], tg, li32, self.alpha, self.gamma, loss_out, dsc,
                         row_src=pack['row_src'] if pack else None, batch_shape=(B, Lq))
         if want_grad:
+            ops.scale_(dsc, self.loss_grad_scale)
             self._backward_native(st, dsc)
         return loss_out[0], st['scores']
 

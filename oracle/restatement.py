@@ -275,8 +275,42 @@ def band_attention(q: Tensor, k: Tensor, v: Tensor, lengths: Tensor, radius: int
     return out
 
 
+def band_attention_blocked(q: Tensor, k: Tensor, v: Tensor, lengths: Tensor, radius: int, block: int = 64) -> Tensor:
+    """The same function as :func:`band_attention` computed block-wise with dense matmuls -- the way HF's
+    ``_sliding_chunks_query_key_matmul`` (HF:759-823) gets its speed: queries in blocks of ``block`` rows, each block against the
+    ``block + 2*radius`` keys it can see, out-of-band entries masked.  Used by bench.py's ``cpu_baseline`` (the shifted-product
+    form above does 2w+1 elementwise passes over q/k/v and is ~2x slower than the reference on CPU); cross-checked against
+    :func:`band_attention` in tests/test_oracle_vs_golden.py."""
+    B, L, Hh, hd = q.shape
+    w = radius
+    nb = (L + block - 1) // block
+    Lp = nb * block
+    pad_q = Lp - L
+    qp = torch.nn.functional.pad(q, (0, 0, 0, 0, 0, pad_q))                                 # [B, Lp, H, hd]
+    kp = torch.nn.functional.pad(k, (0, 0, 0, 0, w, w + pad_q))                             # key j sits at j + w
+    vp = torch.nn.functional.pad(v, (0, 0, 0, 0, w, w + pad_q))
+    span = block + 2 * w
+    kb = kp.unfold(1, span, block)                                                           # [B, nb, H, hd, span]
+    vb = vp.unfold(1, span, block)
+    qb = qp.view(B, nb, block, Hh, hd)
+    s = torch.einsum('bnqhd,bnhdk->bnhqk', qb, kb)                                          # [B, nb, H, block, span]
+    qi = torch.arange(block).view(block, 1)
+    kj = torch.arange(span).view(1, span)
+    in_band = (kj >= qi) & (kj <= qi + 2 * w)                                               # key offset kj <-> j = n*block + kj - w
+    jabs = (torch.arange(nb).view(nb, 1) * block + torch.arange(span).view(1, span) - w)    # [nb, span]
+    key_ok = (jabs.view(1, nb, span) >= 0) & (jabs.view(1, nb, span) < lengths.view(B, 1, 1).clamp(max=L))
+    ok = in_band.view(1, 1, 1, block, span) & key_ok.view(B, nb, 1, 1, span)
+    iabs = torch.arange(Lp).view(1, nb, 1, block, 1)
+    q_ok = iabs < lengths.view(B, 1, 1, 1, 1).clamp(max=L)
+    s = s.masked_fill(~ok, float('-inf'))
+    s = torch.where(q_ok, s, torch.zeros_like(s))
+    pr = torch.softmax(s, dim=-1) * q_ok.to(s.dtype)
+    out = torch.einsum('bnhqk,bnhdk->bnqhd', pr, vb).reshape(B, Lp, Hh, hd)
+    return out[:, :L]
+
+
 def band_encoder(x: Tensor, lengths: Tensor, p: Dict[str, Tensor], heads: int, radii: Sequence[int],
-                 prefix: str = 'model.model.', ln_eps: float = 1e-12) -> Tensor:
+                 prefix: str = 'model.model.', ln_eps: float = 1e-12, attention=None) -> Tensor:
     """``Longformer_Local_Attention.forward`` (models/RestrictedTransformerLayer.py:118-133) =
     HF ``LongformerModel`` with local attention only.
 
@@ -297,8 +331,8 @@ def band_encoder(x: Tensor, lengths: Tensor, p: Dict[str, Tensor], heads: int, r
         q = (h @ p[a + 'query.weight'].t() + p[a + 'query.bias']) / math.sqrt(hd)
         k = h @ p[a + 'key.weight'].t() + p[a + 'key.bias']
         v = h @ p[a + 'value.weight'].t() + p[a + 'value.bias']
-        ctx = band_attention(q.view(B, L, heads, hd), k.view(B, L, heads, hd), v.view(B, L, heads, hd),
-                             lengths, radius).reshape(B, L, D)
+        ctx = (attention or band_attention)(q.view(B, L, heads, hd), k.view(B, L, heads, hd), v.view(B, L, heads, hd),
+                                            lengths, radius).reshape(B, L, D)
         o = lp + 'attention.output.'
         a1 = layer_norm(ctx @ p[o + 'dense.weight'].t() + p[o + 'dense.bias'] + h,
                         p[o + 'LayerNorm.weight'], p[o + 'LayerNorm.bias'], ln_eps)
@@ -314,9 +348,9 @@ def pyramidal_radii(num_layers: int, window: int) -> List[int]:
     return [(k * window) // 2 for k in range(num_layers, 0, -1)]
 
 
-def transformer_scores(x: Tensor, lengths: Tensor, p: Dict[str, Tensor], heads: int, radii: Sequence[int]) -> Tensor:
+def transformer_scores(x: Tensor, lengths: Tensor, p: Dict[str, Tensor], heads: int, radii: Sequence[int], attention=None) -> Tensor:
     """Transformer_segmenter: encoder -> Linear(D -> 1|2).  models/CRF.py:578-579, :601-602."""
-    h = band_encoder(x, lengths, p, heads, radii)
+    h = band_encoder(x, lengths, p, heads, radii, attention=attention)
     return h @ p['classification.weight'].t() + p['classification.bias']
 
 

@@ -88,3 +88,118 @@ def test_shard_batch_partitions_documents():
     ids = sorted(i for p in parts for i in p['id'].tolist())
     assert ids == list(range(B))
     assert shard_batch(b, 0, 1) is b
+
+
+# ---------------------------------------------------------------------------------------------------- round 2
+RAGGED = [12, 3, 7, 12, 1, 9]            # rank 0 gets documents 0, 2, 4 (20 sentences), rank 1 gets 1, 3, 5 (24 sentences)
+
+
+def _make_ragged_batch():
+    b = _make_batch()
+    lengths = torch.tensor(RAGGED)
+    for i, n in enumerate(RAGGED):
+        b['src_tokens'][i, n:] = 0.0
+        b['tgt_tokens'][i, n:] = -1.0
+    b['src_lengths'] = lengths
+    return b
+
+
+def _bilstm_oracle_grads(model, batch):
+    p = {k: v.detach().clone().double().requires_grad_(True) for k, v in model.state_dict().items()}
+    scores = R.bilstm_scores(batch['src_tokens'].double(), batch['src_lengths'], p, 1)
+    loss = R.tagger_loss(scores, batch['src_lengths'], batch['tgt_tokens'].double(), 'FocalLoss')
+    gs = torch.autograd.grad(loss, list(p.values()), allow_unused=True)
+    return loss.item(), {k: (g if g is not None else torch.zeros_like(v)) for (k, v), g in zip(p.items(), gs)}
+
+
+def _make_model(kind):
+    if kind == 'transformer':
+        from multimodaltopicsegmentation_amd.taggers import Transformer_segmenter
+        return Transformer_segmenter(2, D, FF, num_layers=NL, nheads=HEADS, loss_fn='FocalLoss', window_size=WINDOW, compute_dtype='fp32',
+                                     max_position_embedding=64, seed=3), _oracle_grads
+    from multimodaltopicsegmentation_amd.rnn_taggers import BiLSTM
+    return BiLSTM(2, D, 16, num_layers=1, loss_fn='FocalLoss', compute_dtype='fp32', seed=3), _bilstm_oracle_grads
+
+
+def _worker2(rank, world, port, out_dir, kind, token_weighted, xdtype):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from multimodaltopicsegmentation_amd.trainer import NativeTrainer, shard_batch, local_loss_count
+    model, oracle = _make_model(kind)
+    tr = NativeTrainer(model, lr=1e-3, token_weighted=token_weighted, grad_exchange_dtype=xdtype)
+    shard = shard_batch(_make_ragged_batch(), rank, world)
+    assert local_loss_count(model, shard) == sum(RAGGED[rank::world])
+    w = tr.exchange_weight(shard)
+    if token_weighted:
+        assert tr.last_global_count == sum(RAGGED) and abs(w - world * sum(RAGGED[rank::world]) / sum(RAGGED)) < 1e-12
+    else:
+        assert w == 1.0
+    _, grads = oracle(model, shard)
+    views = model.grad_views()
+    for k, g in grads.items():
+        views[k].copy_((g * w).float())          # what the kernels leave in grad_flat when loss_grad_scale = w
+    local = {k: v.clone() for k, v in views.items()}
+    tr._last_L = L
+    tr._check_same_length(L)
+    tr.allreduce_grads()
+    torch.save({'sum': {k: v.clone() for k, v in views.items()}, 'local': local}, os.path.join(out_dir, f'g{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('kind', ['transformer', 'bilstm'])
+def test_token_weighted_exchange_equals_the_single_process_gradient_on_ragged_shards(tmp_path, kind):
+    """SURVEY.md §8(e) caveat (models/CRF.py:352): shard losses are means over 20 and 24 sentences.  token_weighted=True must
+    reproduce the gradient of ONE process holding all six documents; token_weighted=False (DDP's mean of means) must not."""
+    world = 2
+    model, oracle = _make_model(kind)
+    _, full = oracle(model, _make_ragged_batch())
+    for tw in (True, False):
+        out = tmp_path / f'tw{int(tw)}'
+        out.mkdir()
+        mp.spawn(_worker2, args=(world, _free_port(), str(out), kind, tw, 'fp32'), nprocs=world, join=True)
+        g0, g1 = torch.load(out / 'g0.pt')['sum'], torch.load(out / 'g1.pt')['sum']
+        worst = 0.0
+        for k in full:
+            assert torch.equal(g0[k], g1[k]), k
+            ref = full[k].float()
+            err = float(((g0[k] / world) - ref).abs().max()) / max(float(ref.abs().max()), 1e-12)
+            worst = max(worst, err)
+            if tw:
+                assert err < 2e-4, (k, err)
+        if not tw:
+            assert worst > 1e-3, worst            # mean of shard means IS a different gradient on ragged shards
+
+
+def test_length_mismatch_across_ranks_is_an_error_not_a_hang():
+    """_check_same_length with world 1 semantics is trivial; the collective form is covered by the workers above (equal
+    lengths).  Here: the error text names the remedy."""
+    import inspect
+    from multimodaltopicsegmentation_amd.trainer import NativeTrainer
+    assert 'shard_batch' in inspect.getsource(NativeTrainer._check_same_length)
+
+
+@pytest.mark.timeout(300)
+def test_bf16_gradient_exchange_error_bound(tmp_path):
+    """grad_exchange_dtype='bf16': each contribution is rounded to bf16 and the collective adds in bf16, so every element of
+    the exchanged sum is within 2^-8 * sum_r |g_r| (+ one bf16 ulp of the result) of the fp32 sum; both ranks hold the same
+    bits."""
+    world = 2
+    mp.spawn(_worker2, args=(world, _free_port(), str(tmp_path), 'transformer', False, 'bf16'), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / 'g0.pt'), torch.load(tmp_path / 'g1.pt')
+    checked = 0
+    for k in r0['sum']:
+        assert torch.equal(r0['sum'][k], r1['sum'][k]), k
+        exact = r0['local'][k].double() + r1['local'][k].double()
+        mag = r0['local'][k].double().abs() + r1['local'][k].double().abs()
+        if 'position_embeddings' in k:
+            # rows outside [2, L + 2) are not exchanged (never touched by a batch of this length): they keep the local value
+            exact, mag, got = exact[2:L + 2], mag[2:L + 2], r0['sum'][k].double()[2:L + 2]
+        else:
+            got = r0['sum'][k].double()
+        bound = 2.0 ** -8 * mag + 2.0 ** -8 * exact.abs() + 1e-30
+        assert bool(((got - exact).abs() <= bound).all()), k
+        checked += got.numel()
+        # and the rounding is real: the bf16 result is not the fp32 sum everywhere
+    assert checked > 1000

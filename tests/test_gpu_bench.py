@@ -30,6 +30,8 @@ def test_bench_json_contract_transformer():
     r = j['roofline']
     assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s') and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
     assert 'traffic' in r
+    assert j['extra']['sustained_steps'] == 1000 and j['extra']['sustained_value'] > 0
+    assert j['config']['workload'].startswith('variant')            # 8 x 128 is not a BASELINE.json configuration
     c = j['cpu_baseline']
     assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and c['unit'] == 'sentences/s' and 'sample' in c
 
@@ -38,6 +40,7 @@ def test_bench_json_contract_transformer():
 def test_bench_runs_other_architectures(arch):
     j = _run('--arch', arch, '--steps', '2', '--warmup', '1', '--docs', '16', '--seq', '64', '--no-cpu-baseline')
     assert j['value'] > 0 and j['ms_per_step'] > 0
+    assert 'configs[1]' not in j['config']['workload']
 
 
 def test_bench_ragged_counts_valid_sentences_only():

@@ -243,3 +243,28 @@ def test_lstm_init_statistics_fixture():
             assert np.all(v == 0)
         if k.startswith('xavier.'):
             assert v[0] <= v[1] + 1e-6
+
+
+def test_blocked_band_attention_equals_the_shifted_statement():
+    """bench.py's cpu_baseline uses the block-wise matmul form; it must be the same function (values and gradients), ragged
+    lengths, a document shorter than the radius, L not a multiple of the block."""
+    g = torch.Generator().manual_seed(0)
+    for (B, L, Hh, hd, w, block) in ((3, 50, 2, 8, 15, 16), (2, 130, 1, 4, 4, 64), (2, 7, 2, 4, 15, 64)):
+        lengths = torch.randint(1, L + 1, (B,), generator=g)
+        lengths[0] = L
+        q, k, v = (torch.randn(B, L, Hh, hd, generator=g, dtype=torch.float64).requires_grad_(True) for _ in range(3))
+        a = R.band_attention(q, k, v, lengths, w)
+        b = R.band_attention_blocked(q, k, v, lengths, w, block)
+        assert float((a - b).abs().max()) < 1e-12
+        c = torch.randn(a.shape, generator=g, dtype=torch.float64)
+        ga = torch.autograd.grad((a * c).sum(), [q, k, v])
+        gb = torch.autograd.grad((b * c).sum(), [q, k, v])
+        for x, y in zip(ga, gb):
+            assert float((x - y).abs().max()) < 1e-12
+    # and through the whole model on fixture g3b
+    gg = H.load('g3b_transformer_w30')
+    D, heads, ff, NL, window = [int(v) for v in gg['cfg']]
+    p = {k_: _t(H.seeded_param(k_, shp, int(gg['seed']))) for k_, shp in H.band_param_shapes(D, ff, NL, 1).items()}
+    sc = R.transformer_scores(_t(gg['x']), torch.from_numpy(gg['lengths']), p, heads, R.pyramidal_radii(NL, window),
+                              attention=R.band_attention_blocked)
+    np.testing.assert_allclose(sc.numpy(), gg['scores'], atol=2e-5, rtol=0)
