@@ -524,6 +524,7 @@ extern "C" int mts_gemm_last_plan(int* tile, int* splits) {
 }
 
 void mts_band_set_mfma(int on);   // band_attn.hip
+static int g_gemm_variant = 0;               // A/B switch of the big-tile kernels (GemmArgs::variant)
 void mts_lstm_pair_set_spin_limit(int n);   // lstm_pair.hip
 void mts_lstm_pair_set_max_pairs(int n);
 extern "C" int mts_set_option(const char* key, int value) {
@@ -534,6 +535,7 @@ extern "C" int mts_set_option(const char* key, int value) {
   if (!strcmp(key, "gemm_order")) { g_tile_order = value; return MTS_OK; }
   if (!strcmp(key, "gemm_chain")) { g_chain = value; return MTS_OK; }
   if (!strcmp(key, "gemm_deep")) { g_gemm_deep = value; return MTS_OK; }
+  if (!strcmp(key, "gemm_variant")) { g_gemm_variant = value; return MTS_OK; }
   if (!strcmp(key, "band_mfma")) { mts_band_set_mfma(value); return MTS_OK; }
   if (!strcmp(key, "lstm_pair_spin_limit")) { mts_lstm_pair_set_spin_limit(value); return MTS_OK; }
   if (!strcmp(key, "lstm_pair_max_pairs")) { mts_lstm_pair_set_max_pairs(value); return MTS_OK; }
@@ -585,6 +587,10 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.residual = residual; a.aux = aux;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.ldaux = ldaux;
   a.epi = epilogue; a.colscale = colscale; a.ncols_scaled = ncols_scaled;
+  a.variant = g_gemm_variant;
+#ifdef MTS_GEMM_STAMPS
+  a.stamps = nullptr;
+#endif
   a.ksplit = K; a.slab = nullptr; a.chain = nullptr; a.order = g_tile_order; a.nbuf = 2;
 
   if (a_dtype == MTS_F32) {

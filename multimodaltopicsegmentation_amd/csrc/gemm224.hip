@@ -15,9 +15,18 @@
 //     phase 3: DMA B0(t+2) ; read A[rows 32..63]                 ; 12 MFMA  (1,1)
 //     phase 4: DMA B1(t+2) ;                                       16 MFMA  (1,0) ; vmcnt(8) ; barrier
 #include <algorithm>
+#include <type_traits>
 #include <math.h>
 #include "gemm_common.h"
 
+#ifdef MTS_GEMM_STAMPS
+#define STAMP(slot) do { if (a.stamps && tid == 0) { a.stamps[((size_t)blockIdx.x * 8 + round) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+                                                      if ((slot) == 0) a.stamps[((size_t)blockIdx.x * 8 + round) * 8 + 6] = __builtin_amdgcn_s_memrealtime(); \
+                                                      if ((slot) == 3) a.stamps[((size_t)blockIdx.x * 8 + round) * 8 + 5] = __builtin_amdgcn_s_memrealtime(); \
+                                                      if ((slot) == 4) a.stamps[((size_t)blockIdx.x * 8 + round) * 8 + 7] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
 #define HT_BYTES 16384
 // LDS: three A images (2 halves each) | two B images (2 halves each); the bf16 store staging (8 waves x 4 KiB) aliases the third
 // A image, which is idle between a tile's last K-step and the next tile's first
@@ -26,6 +35,11 @@
 #define LDS_TOTAL (3 * A_BYTES + 4 * HT_BYTES)
 #define BN224 224
 #define HN224 112
+
+#ifdef MTS_GEMM_STAMPS
+static unsigned long long* g_gemm_stamps = nullptr;
+extern "C" void mts_gemm_set_stamps(void* p) { g_gemm_stamps = (unsigned long long*)p; }
+#endif
 
 template <bool KMAJOR>
 __device__ __forceinline__ void dma_half(const bf16_t* __restrict__ G, int ld, int row0, int dim, int k0, char* dst, int wave_u, int lane) {
@@ -119,7 +133,95 @@ __device__ __forceinline__ void store_tile_224(const GemmArgs& a, f32x4 (&acc)[4
   }
 }
 
-template <int LAYOUT, typename TC>
+// ---- fast epilogue (full tiles, bf16 C, bias / column scale / residual only) -----------------------------------------------
+// The generic store_tile_224 above evaluates the epilogue flags per 16x16 fragment: 28 bias loads and up to 28 residual loads
+// per wave sit BETWEEN the stores, each behind a compiler-inserted "s_waitcnt vmcnt(0)" (346 of them in the ISA) -- every load
+// waited for the stores issued before it AND for the next tile's first DMAs, so a tile's epilogue ran as ~30 serial memory round
+// trips: 24,400 of a tile's 111,000 cycles for the Q|K|V projection, 50,000 of 139,000 with a residual (in-kernel stamps,
+// tools/gemm_stamps.py).  Here every global load of the epilogue is issued up front, BEFORE the next tile's DMAs (the vector
+// memory counter retires in order: a load behind the DMAs could only be waited for together with them), the stores follow
+// without a single load in between, and nobody waits for the stores until two K-tiles into the next tile (EPI_STORES below).
+
+__device__ __forceinline__ bool epi224_fast_ok(const GemmArgs& a, int bm0) {
+  const unsigned simple = MTS_EPI_BIAS | MTS_EPI_COLSCALE | MTS_EPI_RESIDUAL;
+  return !a.slab && (a.epi & ~simple) == 0 && bm0 + 256 <= a.M && (a.ldc % 8 == 0) && (((uintptr_t)a.C & 15) == 0) &&
+         (!(a.epi & MTS_EPI_COLSCALE) || a.ncols_scaled % 4 == 0) &&
+         (!(a.epi & MTS_EPI_RESIDUAL) || (a.ldr % 4 == 0 && ((uintptr_t)a.residual & 7) == 0)) &&
+         (!(a.epi & MTS_EPI_BIAS) || ((uintptr_t)a.bias & 15) == 0);
+}
+
+// The fast epilogue is BRANCH-FREE so that every vector-memory wait in it can be counted: without a bias / residual the loads
+// still execute, from a few cache lines at the start of A (always mapped, >= 4 KiB), and their values are discarded by a select.
+struct Epi224 {
+  const float* bias_p; const bf16_t* res_p; size_t res_ld; bool has_bias, has_res; float colscale; int ncols_scaled;
+  __device__ __forceinline__ void init(const GemmArgs& a, int m0, int n0, bool first_slice, int lane) {
+    const int r16 = lane & 15, g = lane >> 4;
+    has_bias = (a.epi & MTS_EPI_BIAS) && first_slice;
+    has_res = (a.epi & MTS_EPI_RESIDUAL) && first_slice;
+    bias_p = has_bias ? a.bias + n0 + 4 * g : reinterpret_cast<const float*>(a.A) + 4 * g;
+    res_ld = has_res ? (size_t)a.ldr : 0;
+    res_p = has_res ? reinterpret_cast<const bf16_t*>(a.residual) + (size_t)(m0 + r16) * a.ldr + n0 + 4 * g
+                    : reinterpret_cast<const bf16_t*>(a.A) + 4 * g;
+    colscale = (a.epi & MTS_EPI_COLSCALE) ? a.colscale : 1.0f;
+    ncols_scaled = (a.epi & MTS_EPI_COLSCALE) ? a.ncols_scaled - n0 - 4 * g : 0;
+  }
+  __device__ __forceinline__ void load_bias(float4 (&b)[7]) const {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) b[j] = *reinterpret_cast<const float4*>(bias_p + j * 16);
+  }
+  __device__ __forceinline__ void load_res(int i, uint2 (&r)[7]) const {       // rows m0 + i*16 + r16 of the wave's tile
+#pragma unroll
+    for (int j = 0; j < 7; ++j) r[j] = *reinterpret_cast<const uint2*>(res_p + (size_t)(i * 16) * res_ld + j * 16);
+  }
+  // acc = (acc + bias) * scale for the whole 64 x 112 wave tile
+  __device__ __forceinline__ void fold_bias(f32x4 (&acc)[4][7], const float4 (&b)[7]) const {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const float sc = (j * 16 < ncols_scaled) ? colscale : 1.0f;
+      const float4 bb = has_bias ? b[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[i][j][0] = (acc[i][j][0] + bb.x) * sc;
+        acc[i][j][1] = (acc[i][j][1] + bb.y) * sc;
+        acc[i][j][2] = (acc[i][j][2] + bb.z) * sc;
+        acc[i][j][3] = (acc[i][j][3] + bb.w) * sc;
+      }
+    }
+  }
+  // rows i*16 .. i*16+15 of the wave tile: (+ residual) -> bf16 -> LDS staging -> four 16-byte stores per lane group
+  __device__ __forceinline__ void pass(const GemmArgs& a, const f32x4 (&acc)[7], const uint2 (&r)[7], int i, int m0, int n0, char* stage, int lane) const {
+    const int r16 = lane & 15, g = lane >> 4;
+    bf16_t* __restrict__ C = reinterpret_cast<bf16_t*>(a.C);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const uint2 rr = has_res ? r[j] : make_uint2(0u, 0u);
+      uint2 pk;
+      pk.x = pack_bf16x2(acc[j][0] + bf16_lo(rr.x), acc[j][1] + bf16_hi(rr.x));
+      pk.y = pack_bf16x2(acc[j][2] + bf16_lo(rr.y), acc[j][3] + bf16_hi(rr.y));
+      *reinterpret_cast<uint2*>(stage + r16 * 240 + (j * 16 + 4 * g) * 2) = pk;      // 240-byte rows: 16 B of padding
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = it * 64 + lane;
+      const int row = idx / 14, ch = idx - row * 14;
+      if (idx < 16 * 14) {
+        const uint4 val = *reinterpret_cast<const uint4*>(stage + row * 240 + ch * 16);
+        *reinterpret_cast<uint4*>(C + (size_t)(m0 + i * 16 + row) * a.ldc + n0 + ch * 8) = val;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+};
+
+// PERSIST = false: one tile per workgroup.  The workgroup ends right behind its last store instruction, so the stores drain
+// while the CU's next workgroup starts its K loop, and no state of a next tile lives across the epilogue (the persistent form
+// keeps ~60 registers of it and the fast epilogue spills around every store there).
+// ONEBAR = true: ONE workgroup barrier per K-tile.  A is copied two K-tiles ahead into three images (activations: L2 misses are
+// served by the Infinity Cache / HBM), B only ONE K-tile ahead into two images (weights: L2 hits), issued right behind the
+// barrier that freed its image -- so no image is overwritten inside the K-tile that reads it and the mid-tile barrier (with the
+// burst of LDS reads behind it) is gone.  ONEBAR = false is the round-1 schedule (both operands two ahead, B recycled mid-tile).
+template <int LAYOUT, typename TC, bool PERSIST, bool ONEBAR>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a) {
   constexpr bool A_KMAJOR = (LAYOUT == MTS_NT || LAYOUT == MTS_NN);
   constexpr bool B_KMAJOR = (LAYOUT == MTS_NT || LAYOUT == MTS_TT);
@@ -164,161 +266,235 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a)
   auto dmaB = [&](int h, int kt) {
     dma_half<B_KMAJOR>(B, a.ldb, bn0 + h * HN224, a.N, kbeg + kt * BK, smem + B_BASE + ((kt & 1) * 2 + h) * HT_BYTES, wave_u, lane);
   };
+  // copy instructions per wave and K-tile: 4 for A, 4 for B.  Issue order matters for the counted waits (in-order counter).
+  constexpr int LOOP_LEAD = ONEBAR ? 4 : 8;      // copies of one loop iteration that may still be in flight at its end
   auto prologue = [&]() {
     if (nk > 0) {
       dmaB(0, 0); dmaB(1, 0); dmaA(0, 0, 0); dmaA(1, 0, 0);
-      if (nk > 1) { dmaB(0, 1); dmaB(1, 1); dmaA(0, 1, 1); dmaA(1, 1, 1); }
+      if (nk > 1) {
+        if constexpr (!ONEBAR) { dmaB(0, 1); dmaB(1, 1); }
+        dmaA(0, 1, 1); dmaA(1, 1, 1);
+      }
     }
   };
 
   f32x4 acc[4][7];
-  bf16x8 af[2][2], b0[4][2], b1[3][2];
-  frag_raw raf[2][2], rb0[4][2], rb1[3][2];      // transposed reads in flight (strided operands only; gemm_common.h)
+  LFrag<B_KMAJOR> fb0[4][2], fb1[3][2];          // fragment reads in flight / landed (gemm_common.h)
+  LFrag<A_KMAJOR> faA[2][2], faB[2][2];
   const int arow = (wm & 1) * 64;
 
   int t = blockIdx.x;
   if (t >= nt) return;
   tile_origin(t, bm0, bn0);
+  auto wait_first_tile = [&]() {                 // K-tile 0 has landed: everything but the copies of K-tile 1
+    if (nk > 1) { if constexpr (ONEBAR) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
   prologue();
-  if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // K-tile 0 has landed (a wave issues 8 copy instructions per K-tile)
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wait_first_tile();
   __builtin_amdgcn_s_barrier();
 
   // (A register-pipelined variant -- fragments of phase p+1 fetched from LDS under the MFMAs of phase p, second barrier
   // moved up so that the next K-tile's first fragments are fetched in phase 4 -- measured 5-15 % SLOWER than this simple
   // form on MI355X, so LDS latency is not what holds the K-tile at ~2x its pure MFMA time; see DESIGN.md.)
+  int round = 0;
   for (;;) {
+    STAMP(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 7; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     int ab = 0;                                   // kt % 3
+#pragma clang loop unroll(disable)
     for (int kt = 0; kt < nk; ++kt) {
       const char* At = smem + ab * A_BYTES + (wm >> 1) * HT_BYTES;
       const char* Bt = smem + B_BASE + ((kt & 1) * 2 + wn) * HT_BYTES;
       const int ab2 = ab == 0 ? 2 : ab - 1;       // (kt + 2) % 3: the A image read one K-step ago
 
+      // Fragment reads are asm with counted waits (gemm_common.h "LDS fragment reads the caller waits for").  Per K-tile:
+      //   reads P1 (b0 x8, aA x4) + P2 (b1 x6) issued together; P1's MFMAs start group by group as their fragments land;
+      //   reads P3 (aB x4: A rows 32..63, its own registers) go out before P2's MFMAs, so nothing is read behind barrier 1.
+      constexpr int cb = lfrag_ops<B_KMAJOR>::value, ca = lfrag_ops<A_KMAJOR>::value;
+      constexpr int T1 = 14 * cb + 4 * ca;           // LDS operations of the first block of reads
+
       // ---- phase 1 ---------------------------------------------------------------------------
-      if (kt + 2 < nk) dmaA(0, kt + 2, ab2);
+      if constexpr (ONEBAR) { if (kt + 1 < nk) dmaB(0, kt + 1); }
+      else { if (kt + 2 < nk) dmaA(0, kt + 2, ab2); }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          if constexpr (B_KMAJOR) b0[j][ks] = frag_kmajor(Bt, j * 16 + r16, ks * 4 + g);
-          else rb0[j][ks] = frag_strided(Bt, ks * 32 + 8 * g, j * 16, lane);
+          if constexpr (B_KMAJOR) lfrag_read<B_KMAJOR>(fb0[j][ks], Bt, j * 16 + r16, ks * 4 + g, lane);
+          else lfrag_read<B_KMAJOR>(fb0[j][ks], Bt, ks * 32 + 8 * g, j * 16, lane);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          if constexpr (A_KMAJOR) af[i][ks] = frag_kmajor(At, arow + i * 16 + r16, ks * 4 + g);
-          else raf[i][ks] = frag_strided(At, ks * 32 + 8 * g, arow + i * 16, lane);
+          if constexpr (A_KMAJOR) lfrag_read<A_KMAJOR>(faA[i][ks], At, arow + i * 16 + r16, ks * 4 + g, lane);
+          else lfrag_read<A_KMAJOR>(faA[i][ks], At, ks * 32 + 8 * g, arow + i * 16, lane);
         }
       }
-      if constexpr (!A_KMAJOR || !B_KMAJOR) {            // transposed reads are asm: wait for them by hand (gemm_common.h)
-        lds_frags_wait();
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) if constexpr (!B_KMAJOR) b0[j][ks] = frag_finish(rb0[j][ks]);
-#pragma unroll
-          for (int i = 0; i < 2; ++i) if constexpr (!A_KMAJOR) af[i][ks] = frag_finish(raf[i][ks]);
-        }
-      }
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j][ks], af[i][ks], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-
-      // ---- phase 2 ---------------------------------------------------------------------------
-      if (kt + 2 < nk) dmaA(1, kt + 2, ab2);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          if constexpr (B_KMAJOR) b1[j][ks] = frag_kmajor(Bt, 64 + j * 16 + r16, ks * 4 + g);
-          else rb1[j][ks] = frag_strided(Bt, ks * 32 + 8 * g, 64 + j * 16, lane);
+          if constexpr (B_KMAJOR) lfrag_read<B_KMAJOR>(fb1[j][ks], Bt, 64 + j * 16 + r16, ks * 4 + g, lane);
+          else lfrag_read<B_KMAJOR>(fb1[j][ks], Bt, ks * 32 + 8 * g, 64 + j * 16, lane);
         }
-      if constexpr (!B_KMAJOR) {
-        lds_frags_wait();
+      __builtin_amdgcn_s_setprio(1);
+      {
+        bf16x8 vb[4], va;
+        // ks = 0, rows 0..15: needs b0[0..3][0], aA[0][0]
+        lgkm_wait<T1 - 4 * cb - ca>();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vb[j] = lfrag_get<B_KMAJOR>(fb0[j][0]);
+        va = lfrag_get<A_KMAJOR>(faA[0][0]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb[j], va, acc[0][j], 0, 0, 0);
+        lgkm_wait<T1 - 4 * cb - 2 * ca>();
+        va = lfrag_get<A_KMAJOR>(faA[1][0]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb[j], va, acc[1][j], 0, 0, 0);
+        // ks = 1
+        lgkm_wait<T1 - 8 * cb - 3 * ca>();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vb[j] = lfrag_get<B_KMAJOR>(fb0[j][1]);
+        va = lfrag_get<A_KMAJOR>(faA[0][1]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb[j], va, acc[0][j], 0, 0, 0);
+        lgkm_wait<T1 - 8 * cb - 4 * ca>();
+        va = lfrag_get<A_KMAJOR>(faA[1][1]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb[j], va, acc[1][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+
+      // ---- phase 2 ---------------------------------------------------------------------------
+      if constexpr (ONEBAR) { if (kt + 1 < nk) dmaB(1, kt + 1); }
+      else { if (kt + 2 < nk) dmaA(1, kt + 2, ab2); }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {              // phase 3's A fragments (rows 32..63): read ahead of barrier 1
+          if constexpr (A_KMAJOR) lfrag_read<A_KMAJOR>(faB[i][ks], At, arow + 32 + i * 16 + r16, ks * 4 + g, lane);
+          else lfrag_read<A_KMAJOR>(faB[i][ks], At, ks * 32 + 8 * g, arow + 32 + i * 16, lane);
+        }
+      __builtin_amdgcn_s_setprio(1);
+      {
+        bf16x8 vb1[3][2], va[2][2];
+        lgkm_wait<3 * cb + 4 * ca>();              // b1[*][0]
+#pragma unroll
+        for (int j = 0; j < 3; ++j) vb1[j][0] = lfrag_get<B_KMAJOR>(fb1[j][0]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) va[i][0] = lfrag_get<A_KMAJOR>(faA[i][0]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) acc[i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb1[j][0], va[i][0], acc[i][4 + j], 0, 0, 0);
+        lgkm_wait<4 * ca>();                       // b1[*][1]
+#pragma unroll
+        for (int j = 0; j < 3; ++j) vb1[j][1] = lfrag_get<B_KMAJOR>(fb1[j][1]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) va[i][1] = lfrag_get<A_KMAJOR>(faA[i][1]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) acc[i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb1[j][1], va[i][1], acc[i][4 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        lgkm_wait<0>();
+        if constexpr (!ONEBAR) __builtin_amdgcn_s_barrier();   // every wave is done reading this buffer's B images
+
+        // ---- phase 3 ---------------------------------------------------------------------------
+        if constexpr (ONEBAR) { if (kt + 2 < nk) dmaA(0, kt + 2, ab2); }
+        else { if (kt + 2 < nk) dmaB(0, kt + 2); }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int j = 0; j < 3; ++j) b1[j][ks] = frag_finish(rb1[j][ks]);
-      }
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 3; ++j) acc[i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j][ks], af[i][ks], acc[i][4 + j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();          // every wave is done reading this buffer's B images
-
-      // ---- phase 3 ---------------------------------------------------------------------------
-      if (kt + 2 < nk) dmaB(0, kt + 2);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          if constexpr (A_KMAJOR) af[i][ks] = frag_kmajor(At, arow + 32 + i * 16 + r16, ks * 4 + g);
-          else raf[i][ks] = frag_strided(At, ks * 32 + 8 * g, arow + 32 + i * 16, lane);
-        }
-      if constexpr (!A_KMAJOR) {
-        lds_frags_wait();
+          for (int i = 0; i < 2; ++i) va[i][ks] = lfrag_get<A_KMAJOR>(faB[i][ks]);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int i = 0; i < 2; ++i) af[i][ks] = frag_finish(raf[i][ks]);
-      }
-      __builtin_amdgcn_s_setprio(1);
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 3; ++j) acc[2 + i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j][ks], af[i][ks], acc[2 + i][4 + j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
+            for (int j = 0; j < 3; ++j) acc[2 + i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb1[j][ks], va[i][ks], acc[2 + i][4 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
 
-      // ---- phase 4 ---------------------------------------------------------------------------
-      if (kt + 2 < nk) dmaB(1, kt + 2);
-      __builtin_amdgcn_s_setprio(1);
+        // ---- phase 4 ---------------------------------------------------------------------------
+        if constexpr (ONEBAR) { if (kt + 2 < nk) dmaA(1, kt + 2, ab2); }
+        else { if (kt + 2 < nk) dmaB(1, kt + 2); }
+        bf16x8 vb0[4][2];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+          for (int j = 0; j < 4; ++j) vb0[j][ks] = lfrag_get<B_KMAJOR>(fb0[j][ks]);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j][ks], af[i][ks], acc[2 + i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // all but A(kt+2), B(kt+2) have landed
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb0[j][ks], va[i][ks], acc[2 + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
+      // everything the NEXT K-tile reads has landed: all copies but the youngest LOOP_LEAD of this iteration (A(kt+2), and in the
+      // two-barrier schedule B(kt+2)); near the end of K fewer were issued, so wait for all
+      if (kt + 2 < nk) { if constexpr (ONEBAR) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       ab = ab == 2 ? 0 : ab + 1;
     }
 
+    STAMP(1);
     const int m0 = bm0 + wm * 64, n0 = bn0 + wn * HN224;
+    bool fast = false;
+    if constexpr (sizeof(TC) == 2 && !PERSIST) fast = (a.variant != 1) && epi224_fast_ok(a, bm0);
     t += gridDim.x;
-    const bool more = t < nt;
-    if (more) {
-      tile_origin(t, bm0, bn0);
-      prologue();
+    const bool more = PERSIST && t < nt;
+    if (fast) {
+      // one tile per workgroup.  Issue order (in-order counter: every wait is a count of YOUNGER operations):
+      //   bias(7) res0(7) | res1(7) res2(7) | stores p0(4) | res3(7) | stores p1(4) p2(4) p3(4)
+      Epi224 e;
+      e.init(a, m0, n0, first_slice, lane);
+      float4 bias[7];
+      uint2 r0[7], r1[7], r2[7];
+      e.load_bias(bias);
+      e.load_res(0, r0);
+      STAMP(2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      e.fold_bias(acc, bias);
+      e.load_res(1, r1);
+      e.load_res(2, r2);
+      e.pass(a, acc[0], r0, 0, m0, n0, stage, lane);
+      e.load_res(3, r0);                                               // r0 is free again
+      asm volatile("s_waitcnt vmcnt(11)" ::: "memory");                // res1, res2: older than stores p0 (4) + res3 (7)
+      e.pass(a, acc[1], r1, 1, m0, n0, stage, lane);
+      e.pass(a, acc[2], r2, 2, m0, n0, stage, lane);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                 // res3: older than stores p1, p2
+      e.pass(a, acc[3], r0, 3, m0, n0, stage, lane);
+      STAMP(3);
+      break;                                                           // the stores drain behind the workgroup's end
+    } else {
+      if (more) {
+        tile_origin(t, bm0, bn0);
+        prologue();
+      }
+      STAMP(2);
+      store_tile_224<TC>(a, acc, m0, n0, first_slice, stage, lane);
+      STAMP(3);
+      if (!more) break;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // stores are younger than the DMAs: wait for everything
+      __builtin_amdgcn_s_barrier();
     }
-    store_tile_224<TC>(a, acc, m0, n0, first_slice, stage, lane);
-    if (!more) break;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // stores are younger than the DMAs: wait for everything
-    __builtin_amdgcn_s_barrier();
+    STAMP(4);
+    ++round;
   }
 }
 
-template <int LAYOUT, typename TC>
-static int launch_one(const GemmArgs& a, int splits, hipStream_t st) {
-  auto k = gemm_bf16_224_kernel<LAYOUT, TC>;
+template <int LAYOUT, typename TC, bool PERSIST, bool ONEBAR>
+static int launch_one_p(const GemmArgs& a, int splits, hipStream_t st) {
+  auto k = gemm_bf16_224_kernel<LAYOUT, TC, PERSIST, ONEBAR>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
@@ -326,9 +502,24 @@ static int launch_one(const GemmArgs& a, int splits, hipStream_t st) {
     attr_set = true;
   }
   const int nt = ceil_div(a.M, 256) * (a.N / BN224);
-  const int gx = (splits == 1) ? std::min(nt, 256) : nt;
+  const int gx = (PERSIST && splits == 1) ? std::min(nt, 256) : nt;
+#ifdef MTS_GEMM_STAMPS
+  GemmArgs b = a;
+  b.stamps = g_gemm_stamps;
+  hipLaunchKernelGGL(k, dim3(gx, 1, splits), dim3(512), LDS_TOTAL, st, b);
+  return MTS_OK;
+#endif
   hipLaunchKernelGGL(k, dim3(gx, 1, splits), dim3(512), LDS_TOTAL, st, a);
   return MTS_OK;
+}
+
+// bf16 C: one tile per workgroup (the stores of a tile drain while the CU's next workgroup runs its K loop); fp32 C (weight
+// gradients, split-K slabs): persistent.  gemm_variant 5 selects the two-barrier K loop (A/B).
+template <int LAYOUT, typename TC>
+static int launch_one(const GemmArgs& a, int splits, hipStream_t st) {
+  constexpr bool persist = sizeof(TC) != 2;
+  if (a.variant == 5) return launch_one_p<LAYOUT, TC, persist, false>(a, splits, st);
+  return launch_one_p<LAYOUT, TC, persist, true>(a, splits, st);
 }
 
 // called from mts_gemm (gemm.hip) when N is a multiple of 224 and the 224-wide tiling fills the CUs better

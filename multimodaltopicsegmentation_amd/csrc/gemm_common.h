@@ -19,6 +19,10 @@ struct GemmArgs {
   unsigned* chain; // split-K without slabs (128x128 kernel): per-tile turn counter, zeroed before the launch; slice z adds its
                    // partial tile into C when the counter reads z (fixed order -> bitwise reproducible), then bumps it
   float* slab;     // split-K: slice z stores its fp32 partial tile to slab[z][M][N] (plain stores); reduced afterwards
+  int variant;     // A/B switch of the big-tile kernels (mts_set_option("gemm_variant", v)); 0 = production behaviour
+#ifdef MTS_GEMM_STAMPS
+  unsigned long long* stamps;   // diagnostic build only (tools/gemm_stamps.py): [workgroup][tile round][8] s_memtime / s_memrealtime
+#endif
 };
 
 // activation of the epilogue: erf-GELU (HF intermediate layer) or ReLU (legacy RestrictedTransformerEncoderLayer)
@@ -162,6 +166,7 @@ __device__ __forceinline__ int strided_off(int krow, int col) {
 }
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
 
 __device__ __forceinline__ bf16x8 frag_kmajor(const char* tile, int row, int chunk) {
   return *reinterpret_cast<const bf16x8*>(tile + kmajor_off(row, chunk));
@@ -193,9 +198,43 @@ __device__ __forceinline__ frag_raw frag_strided(const char* tile, int kbase, in
 // after lds_frags_wait(): ties both halves to the wait's position (empty asm), then forms the MFMA operand
 __device__ __forceinline__ bf16x8 frag_finish(frag_raw f) {
   asm volatile("" : "+v"(f.lo), "+v"(f.hi));
-  typedef __attribute__((ext_vector_type(8))) short s16x8;
   s16x8 v = __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(bf16x8, v);
 }
 __device__ __forceinline__ void lds_frags_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// ------------------------------------------------------------------------------------------------
+// LDS fragment reads the CALLER waits for (big-tile kernels)
+// ------------------------------------------------------------------------------------------------
+// Both read forms as inline asm (K-major: one ds_read_b128; strided: two ds_read_b64_tr_b16) so that a phase can issue ALL of
+// its reads -- and the next phase's -- up front and start its first MFMAs behind a COUNTED s_waitcnt lgkmcnt(N) as soon as the
+// fragments those MFMAs need have arrived (LDS returns in order).  Written as plain loads the compiler waits for every
+// outstanding read before the first MFMA of a burst: after a workgroup barrier all 8 waves issue 12 reads each at once and the
+// matrix cores idle until the LAST of the 96 has been served.
+template <bool KMAJOR> struct LFrag { s16x8 k; frag_raw s; };      // one member is live, the other is dead code
+template <bool KMAJOR> struct lfrag_ops { static constexpr int value = KMAJOR ? 1 : 2; };   // LDS operations per fragment
+
+// K-major: fragment of `row`, 16-byte chunk `chunk`; strided: X[k = kbase .. kbase+7][c0 + (lane & 15)]
+template <bool KMAJOR>
+__device__ __forceinline__ void lfrag_read(LFrag<KMAJOR>& f, const char* tile, int row_or_kbase, int chunk_or_c0, int lane) {
+  if constexpr (KMAJOR) {
+    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(tile + kmajor_off(row_or_kbase, chunk_or_c0));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(f.k) : "v"(addr));
+  } else {
+    f.s = frag_strided(tile, row_or_kbase, chunk_or_c0, lane);
+  }
+}
+// after the covering wait: ties the registers to the wait's position and forms the MFMA operand
+template <bool KMAJOR>
+__device__ __forceinline__ bf16x8 lfrag_get(LFrag<KMAJOR>& f) {
+  if constexpr (KMAJOR) {
+    asm volatile("" : "+v"(f.k));
+    return __builtin_bit_cast(bf16x8, f.k);
+  } else {
+    return frag_finish(f.s);
+  }
+}
+template <int N> __device__ __forceinline__ void lgkm_wait() {
+  static_assert(N >= 0, "negative wait count");
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N < 15 ? N : 15) : "memory");     // the counter has 4 bits
+}
