@@ -291,10 +291,10 @@ def main():
                (2, 256): 'gemm_bf16_256_kernel<TN,f32> (256x256) + splitk_reduce_kernel'}
         rocprof_names = {(0, 128): ['void gemm_bf16_kernel<0, bool _Accum, bool, E>(GemmArgs)'], (1, 128): ['void gemm_bf16_kernel<1, bool _Accum, bool, E>(GemmArgs)'],
                          (2, 128): ['void gemm_bf16_kernel<2, float, true>(GemmArgs)', 'splitk_reduce_kernel(float const*, int, int, int, float*, int, int)'],
-                         (0, 224): ['_Z20gemm_bf16_224_kernelILi0EDF16bEv8GemmArgs'], (1, 224): ['_Z20gemm_bf16_224_kernelILi1EDF16bEv8GemmArgs'],
-                         (2, 224): ['void gemm_bf16_224_kernel<2, float>(GemmArgs)', 'splitk_reduce_kernel(float const*, int, int, int, float*, int, int)'],
-                         (2, 256): ['void gemm_bf16_256_kernel<2, float>(GemmArgs)', 'splitk_reduce_kernel(float const*, int, int, int, float*, int, int)'],
-                         (0, 256): ['_Z20gemm_bf16_256_kernelILi0EDF16bEv8GemmArgs'], (1, 256): ['_Z20gemm_bf16_256_kernelILi1EDF16bEv8GemmArgs']}
+                         (0, 224): ['_Z20gemm_bf16_224_kernelILi0EDF16bLb0ELb1EEv8GemmArgs'], (1, 224): ['_Z20gemm_bf16_224_kernelILi1EDF16bLb0ELb1EEv8GemmArgs'],
+                         (2, 224): ['void gemm_bf16_224_kernel<2, float, true, true>(GemmArgs)', 'splitk_reduce_kernel(float const*, int, int, int, float*, int, int)'],
+                         (2, 256): ['void gemm_bf16_256_kernel<2, float, true>(GemmArgs)', 'splitk_reduce_kernel(float const*, int, int, int, float*, int, int)'],
+                         (0, 256): ['_Z20gemm_bf16_256_kernelILi0EDF16bLb0EEv8GemmArgs'], (1, 256): ['_Z20gemm_bf16_256_kernelILi1EDF16bLb0EEv8GemmArgs']}
         def aggregate(summary):
             per_sym, other = {}, {}
             for tag, (n, ms) in summary.items():

@@ -147,10 +147,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
   // staged bf16 epilogue (see below): its residual chunks are fetched NOW so that they arrive under the K loop
   bool vec_ok = false;
   uint4 rres[4][2];
+  float4 bias_lo = make_float4(0.f, 0.f, 0.f, 0.f), bias_hi = bias_lo;      // columns bn0 + wn*64 + (lane & 7)*8 .. +7: the same for every row
   if constexpr (sizeof(TC) == 2) {
     vec_ok = !a.slab && (a.N % 8 == 0) && (a.ldc % 8 == 0) && (((uintptr_t)a.C & 15) == 0) &&
              (!(a.epi & MTS_EPI_RESIDUAL) || ((a.ldr % 8 == 0) && (((uintptr_t)a.residual & 15) == 0))) &&
              (!a.aux || ((a.ldaux % 8 == 0) && (((uintptr_t)a.aux & 15) == 0)));
+    vec_ok = vec_ok && (!(a.epi & MTS_EPI_BIAS) || (((uintptr_t)a.bias & 15) == 0));
+    if (vec_ok && (a.epi & MTS_EPI_BIAS) && blockIdx.z == 0) {
+      const int n = min(bn0 + wn * 64 + (lane & 7) * 8, a.N - 8);
+      bias_lo = *reinterpret_cast<const float4*>(a.bias + n);
+      bias_hi = *reinterpret_cast<const float4*>(a.bias + n + 4);
+    }
     if (vec_ok && (a.epi & MTS_EPI_RESIDUAL) && blockIdx.z == 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -238,6 +245,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
     // after its last barrier) and run the epilogue on 8-column chunks of contiguous rows instead: bias / residual / aux /
     // C move as 16-byte pieces of 128-byte row segments, still one rounding from the fp32 accumulator.
     if (vec_ok) {
+      // every vector-memory load of this kernel (operand copies, the residual / bias chunks fetched before the K loop) is complete
+      // from here on -- said with the BUILTIN so that the compiler's wait insertion knows it too: behind an inline-asm wait it
+      // still puts "s_waitcnt vmcnt(0)" in front of the first use of a prefetched register on every control-flow path of the
+      // loop below, i.e. between the stores, where it waits for the stores (vmcnt = 0, expcnt / lgkmcnt unconstrained)
+      __builtin_amdgcn_s_waitcnt(0x0F70);
       constexpr int RS = 64 * 4 + 16;                       // fp32 row of 64 columns + 16 B padding
       char* stage = smem + wave * (16 * RS);
 #pragma unroll
@@ -254,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
           float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
           const int m = bm0 + wm * 64 + i * 16 + row, n = bn0 + wn * 64 + ch * 8;
           if (m < a.M && n < a.N) {
-            epi_math8(a, m, n, v, first_slice, rres[i][h]);
+            epi_math8(a, m, n, v, first_slice, rres[i][h], bias_lo, bias_hi);
             uint4 pk;
             pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
             *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + (size_t)m * a.ldc + n) = pk;

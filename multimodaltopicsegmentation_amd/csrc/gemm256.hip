@@ -56,6 +56,17 @@ __device__ __forceinline__ void store_tile_256(const GemmArgs& a, f32x4 (&acc)[8
   const bool vec_ok = (a.N % 8 == 0) && (a.ldc % 8 == 0);
   if constexpr (sizeof(TC) == 2) {
     if (!a.slab && vec_ok) {
+      // the bias of this lane's 4 x 4 columns is fetched ONCE, ahead of every store (a load between the stores is waited for
+      // with vmcnt(0), i.e. together with the stores before it), and the compiler is told -- with the builtin, which its wait
+      // insertion understands -- that nothing is outstanding any more (vmcnt = 0; expcnt / lgkmcnt unconstrained)
+      float4 bj[4];
+      const bool pre_bias = (a.epi & MTS_EPI_BIAS) && first_slice && !(a.epi & MTS_EPI_RESIDUAL) && (((uintptr_t)a.bias & 15) == 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        bj[j] = pre_bias ? *reinterpret_cast<const float4*>(a.bias + min(n0 + j * 16 + 4 * g, a.N - 4)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      GemmArgs a2 = a;
+      if (pre_bias) a2.epi = a.epi & ~MTS_EPI_BIAS;
+      __builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll
       for (int pass = 0; pass < 4; ++pass) {
 #pragma unroll
@@ -66,8 +77,8 @@ __device__ __forceinline__ void store_tile_256(const GemmArgs& a, f32x4 (&acc)[8
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int n = n0 + j * 16 + 4 * g;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (m < a.M && n < a.N) epi_math4<bf16_t>(a, m, n, v, first_slice);
+            float v[4] = {acc[i][j][0] + bj[j].x, acc[i][j][1] + bj[j].y, acc[i][j][2] + bj[j].z, acc[i][j][3] + bj[j].w};
+            if (m < a.M && n < a.N) epi_math4<bf16_t>(a2, m, n, v, first_slice);
             const int chunk = (2 * j + (g >> 1)) ^ (row & 7);
             uint2 pk;
             pk.x = pack_bf16x2(v[0], v[1]);
@@ -98,7 +109,8 @@ __device__ __forceinline__ void store_tile_256(const GemmArgs& a, f32x4 (&acc)[8
   }
 }
 
-template <int LAYOUT, typename TC>
+// PERSIST = false (bf16 C): one tile per workgroup, so that a tile's stores drain while the CU's next workgroup runs its K loop
+template <int LAYOUT, typename TC, bool PERSIST>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GemmArgs a) {
   constexpr bool A_KMAJOR = (LAYOUT == MTS_NT || LAYOUT == MTS_NN);
   constexpr bool B_KMAJOR = (LAYOUT == MTS_NT || LAYOUT == MTS_TT);
@@ -274,7 +286,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GemmArgs a)
     // tile's epilogue stores
     const int m0 = bm0 + wm * 128, n0 = bn0 + wn * 64;
     t += gridDim.x;
-    const bool more = t < nt;
+    const bool more = PERSIST && t < nt;
     if (more) {
       tile_origin(t, bm0, bn0);
       prologue();
@@ -288,7 +300,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GemmArgs a)
 
 template <int LAYOUT, typename TC>
 static int launch_one(const GemmArgs& a, int splits, hipStream_t st) {
-  auto k = gemm_bf16_256_kernel<LAYOUT, TC>;
+  constexpr bool PERSIST = sizeof(TC) != 2;
+  auto k = gemm_bf16_256_kernel<LAYOUT, TC, PERSIST>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
@@ -296,7 +309,7 @@ static int launch_one(const GemmArgs& a, int splits, hipStream_t st) {
     attr_set = true;
   }
   const int nt = ceil_div(a.M, 256) * ceil_div(a.N, 256);
-  const int gx = (splits == 1) ? std::min(nt, 256) : nt;      // persistent over tiles when K is not split
+  const int gx = (PERSIST && splits == 1) ? std::min(nt, 256) : nt;      // fp32 C: persistent over tiles when K is not split
   hipLaunchKernelGGL(k, dim3(gx, 1, splits), dim3(512), LDS_TOTAL, st, a);
   return MTS_OK;
 }

@@ -58,11 +58,13 @@ __device__ __forceinline__ void epi_math4(const GemmArgs& a, int m, int n, float
 }
 
 // the same arithmetic on 8 consecutive in-range columns of row m (bf16 activations): 16-byte aux accesses; r = the residual
-// chunk of (m, n), fetched by the caller ahead of the K loop
-__device__ __forceinline__ void epi_math8(const GemmArgs& a, int m, int n, float (&v)[8], bool first_slice, const uint4& r) {
+// chunk of (m, n) and b0/b1 = the bias of columns n..n+7, ALL fetched by the caller ahead of the K loop: a global load between
+// the stores of an epilogue is waited for with "s_waitcnt vmcnt(0)", i.e. together with every store issued before it (the
+// vector-memory counter retires in order) -- eight serial store round trips per tile in the 128x128 kernel before this.
+__device__ __forceinline__ void epi_math8(const GemmArgs& a, int m, int n, float (&v)[8], bool first_slice, const uint4& r,
+                                          const float4& b0, const float4& b1) {
   const unsigned epi = a.epi;
   if ((epi & MTS_EPI_BIAS) && first_slice) {
-    const float4 b0 = *reinterpret_cast<const float4*>(a.bias + n), b1 = *reinterpret_cast<const float4*>(a.bias + n + 4);
     v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
   }
   if (epi & MTS_EPI_COLSCALE) {
