@@ -299,7 +299,8 @@ def test_gradient_ready_spans_are_final_disjoint_and_cover_every_gradient():
         covered[a:b] += 1
     assert int(covered.max()) == 1
     assert torch.count_nonzero(final.cpu()[covered == 0]) == 0
-    assert len(seen) == 2 * 3 + 2                         # per layer: tail block + q/k/v block; embeddings: positions + rest
+    assert len(seen) == 4 * 3 + 2                         # per layer: tail block + one span per q / k / v projection (the last with the
+                                                          # three biases); embeddings: positions + rest
     assert torch.count_nonzero(final) > 0.9 * int(covered.sum())
 
 
