@@ -118,6 +118,32 @@ def cpu_baseline(args, D, ff, heads, window, n_layers):
     return {'value': args.cpu_docs * args.seq / best, 'unit': 'sentences/s', 'cores': cores, 'kind': 'port', 'sample': sample}
 
 
+def infer_latency(args, model, batch, wl, world, rank):
+    """Latency of one predict_step-sized call: forward + greedy decode (Viterbi for the CRF head) + the device-to-host copy of the
+    boundary lists, i.e. what predict.py / test_step wait for per document.  Wall-clock per call (host launch overhead included:
+    at batch 1 the path is launch-bound), median / p95 over --steps calls after --warmup."""
+    model.eval()
+    x, lengths = batch['src_tokens'], batch['src_lengths']
+    x2 = batch.get('src_tokens2')
+    call = (lambda: model(x, x2, lengths)) if x2 is not None else (lambda: model(x, lengths))
+    for _ in range(max(args.warmup, 2)):
+        call()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(args.steps):
+        t0 = time.perf_counter()
+        call()                                   # returns python lists: the call itself synchronises
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med, p95 = ts[len(ts) // 2], ts[min(len(ts) - 1, int(0.95 * len(ts)))]
+    n_sent = int(lengths.sum())
+    if rank == 0:
+        print(json.dumps({'metric': 'inference latency per call (forward + decode + D2H)', 'value': 1e3 * med, 'unit': 'ms', 'p95_ms': 1e3 * p95,
+                          'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'higher_is_better': False, 'dtype': args.dtype,
+                          'data': 'synthetic', 'sentences_per_s': n_sent / med,
+                          'config': {'workload': f'inference: {wl}, {args.docs} document(s) x {args.seq} sentences per call'}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -134,6 +160,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true')
     ap.add_argument('--ragged', action='store_true', help='ragged lengths U{L/4..L} (value counts valid sentences only)')
+    ap.add_argument('--infer', action='store_true', help='inference latency instead of the training step: model(x, lengths) -> scores + boundary lists '
+                    '(predict_step, lightning_model.py:678-683; the reference decodes test documents with batch_size=1, train_fit.py:154); '
+                    'typical use: --infer --docs 1 --seq 2437 (the longest RadioNews document)')
     ap.add_argument('--no-pack', action='store_true', help='with --ragged: keep the padded rows in the encoder (A/B of the packed training path)')
     args = ap.parse_args()
 
@@ -208,6 +237,9 @@ def main():
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
+
+    if args.infer:
+        return infer_latency(args, model, batch, wl, world, rank)
 
     # Warm-up with every GEMM / band-attention launch bracketed by HIP events: finds the dominant kernel symbol and fills the
     # per-kernel table.  An event pair costs a few microseconds of stream time (14 timed launches = ~5 % of this step), so the

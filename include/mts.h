@@ -99,6 +99,11 @@ int mts_colsum(void* stream, int dtype, int M, int N, const void* X, int ldx, fl
 
 /* fp32 -> act dtype copy (weights to bf16), n elements */
 int mts_cast(void* stream, int dst_dtype, const float* src, void* dst, size_t n);
+/* K-SPLIT INPUT.  Early fusion in the reference is a host-side torch.cat of the text and audio embedding matrices of a document
+ * (utils/load_datasets_precomputed.py:158-161).  The *2 / _concat entry points take the two fp32 matrices separately
+ * (src1 [rows, D1] | src2 [rows, D2], D1 and D2 multiples of 4) so that the concatenated batch never exists: dst [rows, D1+D2] in the
+ * act dtype for the recurrent taggers' first projection ... */
+int mts_cast_concat(void* stream, int dst_dtype, size_t rows, int D1, int D2, const float* src1, const float* src2, void* dst);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm family (biased variance, eps inside sqrt).
@@ -110,6 +115,10 @@ int mts_cast(void* stream, int dst_dtype, const float* src, void* dst, size_t n)
 int mts_embed_layernorm_fwd(void* stream, int dtype, int B, int L, int D, const float* x, const float* pos,
                             int pos_offset, const float* type0, const float* gamma, const float* beta, float eps,
                             void* y, void* pre, float* mean, float* rstd, const int32_t* row_src, int n_rows);
+/* ... and the same embedding + LayerNorm as mts_embed_layernorm_fwd on x = x1[b,i,0:D1] | x2[b,i,0:D2] (D = D1 + D2). */
+int mts_embed_layernorm_fwd2(void* stream, int dtype, int B, int L, int D1, int D2, const float* x1, const float* x2, const float* pos,
+                             int pos_offset, const float* type0, const float* gamma, const float* beta, float eps,
+                             void* y, void* pre, float* mean, float* rstd, const int32_t* row_src, int n_rows);
 /* If head_w != NULL the tagger head is fused in: scores[r,c] = y[r,:].head_w[c,:] + head_b[c] (fp32 [rows,n_out],
  * n_out <= 4), computed on the stored (act dtype) y.  models/CRF.py:579 on top of modeling_longformer.py:1127-1131. */
 int mts_layernorm_fwd(void* stream, int dtype, int rows, int D, const void* x, const float* gamma,

@@ -475,9 +475,35 @@ template <typename T> __global__ void cast_kernel(const float* __restrict__ src,
     for (size_t j = i; j < n; ++j) dst[j] = from_f32<T>(src[j]);
 }
 
+// dst[r, :] = bf16/f32( src1[r, 0:D1] | src2[r, 0:D2] ): the early-fusion concat and the fp32 -> act-dtype cast in one pass over two
+// separate fp32 matrices (the recurrent taggers' K-split input; D1, D2 multiples of 4)
+template <typename T> __global__ void cast_concat_kernel(const float* __restrict__ s1, const float* __restrict__ s2, T* __restrict__ dst,
+                                                          size_t rows, int D1, int D2) {
+  const int D = D1 + D2, q = D / 4;
+  const size_t total = rows * q;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / q;
+    const int e = (int)(i - r * q) * 4;
+    float v[4];
+    load4<float>(e < D1 ? s1 + r * D1 + e : s2 + r * D2 + (e - D1), v);
+    store4<T>(dst + r * D + e, v);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+extern "C" int mts_cast_concat(void* stream, int dst_dtype, size_t rows, int D1, int D2, const float* src1, const float* src2, void* dst) {
+  MTS_CHECK_ARG(src1 && src2 && dst && D1 > 0 && D2 > 0 && D1 % 4 == 0 && D2 % 4 == 0, "mts_cast_concat: bad arguments (widths must be multiples of 4)");
+  if (rows == 0) return MTS_OK;
+  const int blocks = (int)std::min<size_t>(4096, (rows * ((D1 + D2) / 4) + 255) / 256);
+  if (dst_dtype == MTS_BF16) hipLaunchKernelGGL(cast_concat_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src1, src2, (bf16_t*)dst, rows, D1, D2);
+  else if (dst_dtype == MTS_F32) hipLaunchKernelGGL(cast_concat_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src1, src2, (float*)dst, rows, D1, D2);
+  else { mts_set_error("mts_cast_concat: bad dtype %d", dst_dtype); return MTS_ERR_INVALID; }
+  MTS_LAUNCH_CHECK("mts_cast_concat");
+  return MTS_OK;
+}
+
 extern "C" size_t mts_colsum_workspace(int N) { return (size_t)COLSUM_RS * (size_t)N * sizeof(float); }
 
 extern "C" int mts_colsum(void* stream, int dtype, int M, int N, const void* X, int ldx, float* out, int accumulate,

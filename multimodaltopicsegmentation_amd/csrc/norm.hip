@@ -63,7 +63,7 @@ __global__ __launch_bounds__(64 * ROW_WAVES) void ln_fwd_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int rows, int D,
     T* __restrict__ y, T* __restrict__ pre, float* __restrict__ mean_out, float* __restrict__ rstd_out,
     const float* __restrict__ head_w, const float* __restrict__ head_b, int n_out, float* __restrict__ scores,
-    const int32_t* __restrict__ row_src) {
+    const int32_t* __restrict__ row_src, const float* __restrict__ xin2 = nullptr, int D1 = 0) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * ROW_WAVES + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -71,14 +71,18 @@ __global__ __launch_bounds__(64 * ROW_WAVES) void ln_fwd_kernel(
   if constexpr (EMBED) {
     // packed batches: output row `row` is sentence row_src[row] = b*L + i of the padded batch (position = i)
     const int src = row_src ? row_src[row] : row;
-    const float* xr = reinterpret_cast<const float*>(xin) + (size_t)src * D;
+    // K-split input (xin2 != NULL): the row is text[src, 0:D1] | audio[src, 0:D-D1], two separate matrices -- the early-fusion
+    // concat of utils/load_datasets_precomputed.py:158-161 is never materialised; D1 % 4 == 0, so no 16-byte chunk straddles
+    const int Dx = xin2 ? D1 : D;
+    const float* xr = reinterpret_cast<const float*>(xin) + (size_t)src * Dx;
+    const float* xr2 = xin2 ? xin2 + (size_t)src * (D - D1) - D1 : xr;
     const float* pr = pos + (size_t)(pos_offset + src % L) * D;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int e = 4 * (lane + 64 * i);
       if (FULL || e < D) {
         float a[4], b[4], c[4];
-        load4<float>(xr + e, a); load4<float>(pr + e, b); load4<float>(type0 + e, c);
+        load4<float>((e < Dx ? xr : xr2) + e, a); load4<float>(pr + e, b); load4<float>(type0 + e, c);
 #pragma unroll
         for (int j = 0; j < 4; ++j) x[i][j] = (a[j] + b[j]) + c[j];   // same association as HF:421
         if constexpr (sizeof(T) == 2) {
@@ -580,7 +584,8 @@ template <typename F> static inline void dispatch_nv8(int nv, F&& f) {   // kern
 template <typename T, bool EMBED>
 static int ln_fwd_launch(hipStream_t st, const void* x, const float* pos, int pos_offset, int L, const float* type0, const float* gamma,
                          const float* beta, float eps, int rows, int D, void* y, void* pre, float* mean, float* rstd,
-                         const float* head_w, const float* head_b, int n_out, float* scores, const int32_t* row_src = nullptr) {
+                         const float* head_w, const float* head_b, int n_out, float* scores, const int32_t* row_src = nullptr,
+                         const float* x2 = nullptr, int D1 = 0) {
   const int nv = pick_nv(D);
   MTS_UNSUPPORTED(nv > 0 && D % 4 == 0, "layernorm: D=%d must be a multiple of 4 and <= 4096", D);
   dim3 grid(ceil_div(rows, ROW_WAVES)), block(64 * ROW_WAVES);
@@ -588,29 +593,45 @@ static int ln_fwd_launch(hipStream_t st, const void* x, const float* pos, int po
     constexpr int NV = decltype(nvc)::value;
     if (D == NV * 256)
       hipLaunchKernelGGL((ln_fwd_kernel<T, NV, EMBED, true>), grid, block, 0, st, x, pos, pos_offset, L, type0, gamma, beta, eps, rows, D, (T*)y,
-                         (T*)pre, mean, rstd, head_w, head_b, n_out, scores, row_src);
+                         (T*)pre, mean, rstd, head_w, head_b, n_out, scores, row_src, x2, D1);
     else
       hipLaunchKernelGGL((ln_fwd_kernel<T, NV, EMBED>), grid, block, 0, st, x, pos, pos_offset, L, type0, gamma, beta, eps, rows, D, (T*)y,
-                         (T*)pre, mean, rstd, head_w, head_b, n_out, scores, row_src);
+                         (T*)pre, mean, rstd, head_w, head_b, n_out, scores, row_src, x2, D1);
   });
   MTS_LAUNCH_CHECK("layernorm_fwd");
   return MTS_OK;
 }
 
-extern "C" int mts_embed_layernorm_fwd(void* stream, int dtype, int B, int L, int D, const float* x, const float* pos, int pos_offset,
-                                       const float* type0, const float* gamma, const float* beta, float eps, void* y, void* pre,
-                                       float* mean, float* rstd, const int32_t* row_src, int n_rows) {
-  MTS_CHECK_ARG(B > 0 && L > 0 && D > 0 && x && pos && type0 && gamma && beta && y, "mts_embed_layernorm_fwd: bad arguments");
-  MTS_CHECK_ARG(!row_src || (n_rows > 0 && n_rows <= B * L), "mts_embed_layernorm_fwd: packed form needs 0 < n_rows <= B*L");
+static int embed_ln_fwd(void* stream, int dtype, int B, int L, int D, const float* x, const float* x2, int D1, const float* pos, int pos_offset,
+                        const float* type0, const float* gamma, const float* beta, float eps, void* y, void* pre, float* mean, float* rstd,
+                        const int32_t* row_src, int n_rows, const char* who) {
+  MTS_CHECK_ARG(B > 0 && L > 0 && D > 0 && x && pos && type0 && gamma && beta && y, "%s: bad arguments", who);
+  MTS_CHECK_ARG(!row_src || (n_rows > 0 && n_rows <= B * L), "%s: packed form needs 0 < n_rows <= B*L", who);
+  MTS_CHECK_ARG(!x2 || (D1 > 0 && D1 < D && D1 % 4 == 0), "%s: the first part's width must be a multiple of 4 inside (0, D)", who);
   const int rows = row_src ? n_rows : B * L;
   if (dtype == MTS_F32)
     return ln_fwd_launch<float, true>((hipStream_t)stream, x, pos, pos_offset, L, type0, gamma, beta, eps, rows, D, y, pre, mean, rstd,
-                                      nullptr, nullptr, 0, nullptr, row_src);
+                                      nullptr, nullptr, 0, nullptr, row_src, x2, D1);
   if (dtype == MTS_BF16)
     return ln_fwd_launch<bf16_t, true>((hipStream_t)stream, x, pos, pos_offset, L, type0, gamma, beta, eps, rows, D, y, pre, mean, rstd,
-                                       nullptr, nullptr, 0, nullptr, row_src);
-  mts_set_error("mts_embed_layernorm_fwd: bad dtype %d", dtype);
+                                       nullptr, nullptr, 0, nullptr, row_src, x2, D1);
+  mts_set_error("%s: bad dtype %d", who, dtype);
   return MTS_ERR_INVALID;
+}
+
+extern "C" int mts_embed_layernorm_fwd(void* stream, int dtype, int B, int L, int D, const float* x, const float* pos, int pos_offset,
+                                       const float* type0, const float* gamma, const float* beta, float eps, void* y, void* pre,
+                                       float* mean, float* rstd, const int32_t* row_src, int n_rows) {
+  return embed_ln_fwd(stream, dtype, B, L, D, x, nullptr, 0, pos, pos_offset, type0, gamma, beta, eps, y, pre, mean, rstd, row_src, n_rows,
+                      "mts_embed_layernorm_fwd");
+}
+
+extern "C" int mts_embed_layernorm_fwd2(void* stream, int dtype, int B, int L, int D1, int D2, const float* x1, const float* x2, const float* pos,
+                                        int pos_offset, const float* type0, const float* gamma, const float* beta, float eps, void* y, void* pre,
+                                        float* mean, float* rstd, const int32_t* row_src, int n_rows) {
+  MTS_CHECK_ARG(x2 && D2 > 0 && D2 % 4 == 0, "mts_embed_layernorm_fwd2: second part missing or its width not a multiple of 4");
+  return embed_ln_fwd(stream, dtype, B, L, D1 + D2, x1, x2, D1, pos, pos_offset, type0, gamma, beta, eps, y, pre, mean, rstd, row_src, n_rows,
+                      "mts_embed_layernorm_fwd2");
 }
 
 extern "C" int mts_layernorm_fwd(void* stream, int dtype, int rows, int D, const void* x, const float* gamma, const float* beta, float eps,

@@ -16,6 +16,13 @@ Mirror of ``utils/load_datasets_precomputed.py:56-224`` in the reference:
 
 Items are ``(embeddings float tensor [n, dim], labels list[int], file name)`` tuples, what ``AudioPortionDataset``
 (encoder_dataset.py) consumes.
+
+K-split loading (extension, ``split_modalities=True``): with exactly two ``+``-joined directories the feature-axis concat is NOT
+made; an item is ``(embeddings of the first directory, labels, file name, embeddings of the second directory)`` -- the first three
+fields as above, so every consumer of the reference's items keeps working -- and ``second_input_of(items)`` turns the fourth into
+the ``second_input=`` list of ``AudioPortionDataset``, whose collater then emits ``src_tokens`` and ``src_tokens2`` side by side.
+``TextSegmenter(..., ksplit=True)`` hands that pair to an early-fusion model as one input of width D1 + D2 (the kernels read both
+parts: mts_embed_layernorm_fwd2 / mts_cast_concat), so the concatenated batch exists neither on the host nor in HBM.
 """
 import json
 import os
@@ -44,14 +51,21 @@ def cross_validation_split(dataset, num_folds=5, n_test_folds=1):
     return folds
 
 
-def _load_doc(directories, file):
+def _load_doc(directories, file, split_modalities=False):
     parts = [torch.from_numpy(np.load(os.path.join(root, file)).squeeze()) for root in directories]
-    return torch.cat(parts, dim=-1)
+    if split_modalities:
+        return parts[0], parts[1]
+    return torch.cat(parts, dim=-1), None
+
+
+def second_input_of(items):
+    """``second_input=`` list for AudioPortionDataset from items loaded with split_modalities=True."""
+    return [(it[3], None, it[2]) for it in items]
 
 
 def load_dataset_from_precomputed(embedding_directory, lab_file, delete_last_sentence=False, compute_confidence_intervals=False,
                                   inverse_augmentation=False, umap_project=False, k_folds=5, mask_inner_sentences=False,
-                                  mask_probability=0.9, split=None, timing_info=None):
+                                  mask_probability=0.9, split=None, timing_info=None, split_modalities=False):
     if inverse_augmentation or umap_project:
         raise NotImplementedError('inverse_augmentation / umap_project are outside the hot path (SURVEY.md §8f)')
     standard_split = split is not None
@@ -71,6 +85,9 @@ def load_dataset_from_precomputed(embedding_directory, lab_file, delete_last_sen
         with open(timing_info, 'rb') as f:
             times = pickle.load(f)
     directories = embedding_directory.split('+')
+    if split_modalities and (len(directories) != 2 or timing_info is not None or mask_inner_sentences):
+        raise ValueError('split_modalities=True needs exactly two "+"-joined embedding directories and neither timing_info nor '
+                         'mask_inner_sentences')
     for file in os.listdir(directories[0]):
         if file[-16:] == ':Zone.Identifier' or file[:-4] in _SKIP_STEMS:
             continue
@@ -82,7 +99,7 @@ def load_dataset_from_precomputed(embedding_directory, lab_file, delete_last_sen
                 file, bucket = split['test'].pop(), 1
             else:
                 file, bucket = split['validation'].pop(), 2
-        embs = _load_doc(directories, file)
+        embs, embs2 = _load_doc(directories, file, split_modalities)
         stem = file[:-4]
         if times is not None:
             embs = torch.cat((embs, torch.tensor(times[stem])), dim=-1)
@@ -103,7 +120,7 @@ def load_dataset_from_precomputed(embedding_directory, lab_file, delete_last_sen
             labs[stem] = kept_labs
         if sum(labs[stem]) < 1:
             print('Warning: {} has no positive topic boundaries'.format(stem))
-        item = (embs, labs[stem], file)
+        item = (embs, labs[stem], file) if embs2 is None else (embs, labs[stem], file, embs2)
         if standard_split:
             data[bucket].append(item)
         else:

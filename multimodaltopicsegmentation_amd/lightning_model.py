@@ -50,9 +50,14 @@ class TextSegmenter(_Base):
                  architecture='biLSTMCRF', lr=0.01, dropout_in=0.0, dropout_out=0.0, optimizer='SGD', positional_encoding=True,
                  nheads=8, end_boundary=False, threshold=None, search_threshold=False, metric='Pk', cosine_loss=False,
                  zero_baseline=False, loss_fn='CrossEntropy', no_validation=False, all_results=False, all_scores=False, alpha=0.9,
-                 gamma=2, attention_window=120, switch='dense', compute_dtype=None):
+                 gamma=2, attention_window=120, switch='dense', compute_dtype=None, ksplit=False):
         super().__init__()
         self.validation = not no_validation
+        # ksplit=True (extension, default off): an early-fusion model takes the batch's two embedding tensors ('src_tokens' = text,
+        # 'src_tokens2' = audio, as AudioPortionDataset(second_input=...) collates them) as ONE input of width D1 + D2 without the
+        # host-side concat of utils/load_datasets_precomputed.py:158-161 ever being made (datasets.load_dataset_from_precomputed(
+        # ..., split_modalities=True) keeps the two directories apart)
+        self.ksplit = bool(ksplit)
         self.cos = cosine_loss
         self.double_input = False
         self.domain = False
@@ -101,9 +106,15 @@ class TextSegmenter(_Base):
     def forward(self, x):
         return self.model(x)
 
+    def _sentence(self, batch):
+        """The model input of a batch: 'src_tokens', or the (text, audio) pair when ksplit is on and the batch carries both."""
+        if self.ksplit and not self.double_input and batch.get('src_tokens2') is not None:
+            return (batch['src_tokens'], batch['src_tokens2'])
+        return batch['src_tokens']
+
     # ---- lightning_model.py:273-309 -------------------------------------------------------------------
     def training_step(self, batch, batch_idx):
-        sentence, target, lengths = batch['src_tokens'], batch['tgt_tokens'], batch['src_lengths']
+        sentence, target, lengths = self._sentence(batch), batch['tgt_tokens'], batch['src_lengths']
         segments = batch['src_segments'] if self.cos else None
         self.best_th, self.losses, self.targets = [], [], []
         if self.double_input:
@@ -122,7 +133,7 @@ class TextSegmenter(_Base):
 
     # ---- lightning_model.py:320-351 -------------------------------------------------------------------
     def validation_step(self, batch, batch_idx):
-        sentence, target, lengths = batch['src_tokens'], batch['tgt_tokens'], batch['src_lengths']
+        sentence, target, lengths = self._sentence(batch), batch['tgt_tokens'], batch['src_lengths']
         if self.s_th:
             if self.double_input:
                 scores, tags = self.model(sentence, batch['src_tokens2'], lengths)
@@ -142,7 +153,7 @@ class TextSegmenter(_Base):
 
     # ---- lightning_model.py:558-676 -------------------------------------------------------------------
     def test_step(self, batch, batch_idx):
-        sentence, target, lengths = batch['src_tokens'], batch['tgt_tokens'], batch['src_lengths']
+        sentence, target, lengths = self._sentence(batch), batch['tgt_tokens'], batch['src_lengths']
         if self.s_th:
             raise NotImplementedError()                                      # lightning_model.py:570
         score = None
@@ -201,7 +212,7 @@ class TextSegmenter(_Base):
             # the reference calls model(sentence, lengths) here and raises TypeError for late-fusion models; serve them instead
             score, tags = self.model(batch['src_tokens'], batch['src_tokens2'], batch['src_lengths'])
         else:
-            score, tags = self.model(batch['src_tokens'], batch['src_lengths'])
+            score, tags = self.model(self._sentence(batch), batch['src_lengths'])
         return tags
 
     # ---- lightning_model.py:759-781 -------------------------------------------------------------------

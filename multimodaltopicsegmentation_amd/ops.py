@@ -129,9 +129,21 @@ def cast(src, dst):
     return dst
 
 
-def embed_layernorm_fwd(x, pos, pos_offset, type0, gamma, beta, eps, y, pre, mean, rstd, row_src=None):
-    """row_src (int32 [n_rows], optional): packed batch -- output row r is sentence row_src[r] = b*L + i of x."""
+def cast_concat(x1, x2, dst):
+    """dst[r] = act-dtype(x1[r] | x2[r]) for two fp32 matrices of equal row count (K-split input of the recurrent taggers)."""
+    check(lib.mts_cast_concat(stream_ptr(), dtype_code(dst.dtype), x1.shape[0], x1.shape[1], x2.shape[1], ptr(x1), ptr(x2), ptr(dst)))
+    return dst
+
+
+def embed_layernorm_fwd(x, pos, pos_offset, type0, gamma, beta, eps, y, pre, mean, rstd, row_src=None, x2=None):
+    """row_src (int32 [n_rows], optional): packed batch -- output row r is sentence row_src[r] = b*L + i of x.
+    x2 (fp32 [B, L, D2], optional): K-split input -- the row is x[b, i] | x2[b, i] and the concatenation is never materialised."""
     B, Lq, D = x.shape
+    if x2 is not None:
+        check(lib.mts_embed_layernorm_fwd2(stream_ptr(), dtype_code(y.dtype), B, Lq, D, x2.shape[2], ptr(x), ptr(x2), ptr(pos), pos_offset,
+                                           ptr(type0), ptr(gamma), ptr(beta), eps, ptr(y), ptr(pre), ptr(mean), ptr(rstd), ptr(row_src),
+                                           row_src.numel() if row_src is not None else 0))
+        return
     check(lib.mts_embed_layernorm_fwd(stream_ptr(), dtype_code(y.dtype), B, Lq, D, ptr(x), ptr(pos), pos_offset, ptr(type0),
                                       ptr(gamma), ptr(beta), eps, ptr(y), ptr(pre), ptr(mean), ptr(rstd), ptr(row_src),
                                       row_src.numel() if row_src is not None else 0))

@@ -159,12 +159,14 @@ class _RnnTaggerBase(_TaggerBase):
                                       'raises TypeError (PackedSequence handed to nn.Linear) on every tagger call with this option')
 
     def _prep_input(self, xs, lengths):
-        """pad_packed_sequence semantics: the output covers max(lengths) positions (NeuralArchitectures.py:115)."""
-        B, Lin, _ = xs.shape
+        """pad_packed_sequence semantics: the output covers max(lengths) positions (NeuralArchitectures.py:115).
+        ``xs`` may be a K-split pair (taggers._split_input): both parts are trimmed, the pair is returned."""
+        x1, x2, B, Lin, _ = self._split_input(xs)
         maxlen = int(lengths.max()) if lengths is not None else Lin
         maxlen = min(maxlen, Lin)
-        x = xs[:, :maxlen].contiguous()
-        return x, maxlen
+        if x2 is not None:
+            return (x1[:, :maxlen].contiguous(), x2[:, :maxlen].contiguous()), maxlen
+        return x1[:, :maxlen].contiguous(), maxlen
 
     def _drop_seed(self):
         """A fresh 64-bit seed per dropout call, derived from torch's seed (torch.manual_seed makes runs repeatable)."""
@@ -190,6 +192,13 @@ class _RnnTaggerBase(_TaggerBase):
         return out, mask
 
     def _to_act(self, x):
+        if isinstance(x, tuple):                                       # K-split pair: concat + cast in one pass over the two fp32 parts
+            a, b = (t.reshape(-1, t.shape[-1]).to(torch.float32).contiguous() for t in x)
+            D = a.shape[1] + b.shape[1]
+            if D % 8 == 0:
+                out = self._ws.get('xin_' + str(D), a.shape[0], D, self.compute_dtype, a.device)
+                return ops.cast_concat(a, b, out)
+            x = torch.cat((a, b), dim=1)                               # odd widths (timing features): the padded path below
         x2 = x.reshape(-1, x.shape[-1])
         if x2.shape[1] % 8:                                           # e.g. 768 + 2 timing features: zero columns up to a multiple of 8
             x2 = torch.nn.functional.pad(x2.to(torch.float32), (0, round_up(x2.shape[1], 8) - x2.shape[1]))
@@ -224,18 +233,19 @@ class BiLSTM(_RnnTaggerBase):
 
     def _fwd(self, xs, lengths):
         x, Lq = self._prep_input(xs, lengths)
-        B = x.shape[0]
-        li32 = self._prep_lengths(lengths, B, Lq, xs.device)
+        first = x[0] if isinstance(x, tuple) else x
+        B, dev = first.shape[0], first.device
+        li32 = self._prep_lengths(lengths, B, Lq, dev)
         h, saved = self._rnn.forward(self._drop_in(self._to_act(x), 'r'), li32, B, Lq)
         h, hmask = self._drop_out(h, 'r')
-        scores = self._ws.get('scores', B * Lq, self.n_out, torch.float32, xs.device)
+        scores = self._ws.get('scores', B * Lq, self.n_out, torch.float32, dev)
         ops.head_fwd(h, self._w(self._flat, 'classification.weight'), self._w(self._flat, 'classification.bias'), scores)
         return dict(B=B, L=Lq, li32=li32, h=h, hmask=hmask, saved=saved, scores=scores.view(B, Lq, self.n_out))
 
     def loss_and_grad(self, xs, lengths, tags, want_grad=True):
         L.require_gpu()
         st = self._fwd(xs, lengths)
-        dev, B, Lq = xs.device, st['B'], st['L']
+        dev, B, Lq = st['scores'].device, st['B'], st['L']
         tg = tags.to(device=dev, dtype=torch.float32).contiguous()
         if self.loss_kind == L.LOSS_CE and tg.shape[1] != Lq:
             # the reference reshapes x [B*maxlen, 2] against tags [B*L] (CRF.py:354) and fails on a size mismatch
@@ -419,18 +429,19 @@ class BiRnnCrf(_RnnTaggerBase):
 
     def _fwd(self, xs, lengths):
         x, Lq = self._prep_input(xs, lengths)
-        B = x.shape[0]
-        li32 = self._prep_lengths(lengths, B, Lq, xs.device)
+        first = x[0] if isinstance(x, tuple) else x
+        B, dev = first.shape[0], first.device
+        li32 = self._prep_lengths(lengths, B, Lq, dev)
         h, saved = self._rnn.forward(self._drop_in(self._to_act(x), 'r'), li32, B, Lq)
         h, hmask = self._drop_out(h, 'r')
-        feats = self._ws.get('feats', B * Lq, self.num_tags, torch.float32, xs.device)
+        feats = self._ws.get('feats', B * Lq, self.num_tags, torch.float32, dev)
         ops.head_fwd(h, self._w(self._flat, 'crf.fc.weight'), self._w(self._flat, 'crf.fc.bias'), feats)
         return dict(B=B, L=Lq, li32=li32, h=h, hmask=hmask, saved=saved, feats=feats.view(B, Lq, self.num_tags))
 
     def loss_and_grad(self, xs, lengths, tags, want_grad=True):
         L.require_gpu()
         st = self._fwd(xs, lengths)
-        dev, B, Lq, C = xs.device, st['B'], st['L'], self.num_tags
+        dev, B, Lq, C = st['feats'].device, st['B'], st['L'], self.num_tags
         tg = tags.to(device=dev, dtype=torch.float32).contiguous()
         loss_out = torch.empty(2, dtype=torch.float32, device=dev)
         g, lay = self.grad_flat(), self._layout
@@ -461,8 +472,8 @@ class BiRnnCrf(_RnnTaggerBase):
         with torch.no_grad():
             st = self._fwd(xs, lenghts)
             B, Lq = st['B'], st['L']
-            score = torch.empty(B, dtype=torch.float32, device=xs.device)
-            paths = torch.empty(B, Lq, dtype=torch.int32, device=xs.device)
+            score = torch.empty(B, dtype=torch.float32, device=st['feats'].device)
+            paths = torch.empty(B, Lq, dtype=torch.int32, device=st['feats'].device)
             ops.crf_viterbi(st['feats'], st['li32'], self._w(self._flat, 'crf.transitions'), score, paths)
             ph = paths.cpu().numpy()
             L.check_async()            # synchronised by the copy: report a CU-pair LSTM timeout of this forward instead of its paths

@@ -137,6 +137,20 @@ class _TaggerBase(FlatModule):
         return wflat[off:off + n].view(rows, cols)
 
     @staticmethod
+    def _split_input(xs):
+        """K-split input: ``xs`` may be a pair (text [B, L, D1], audio [B, L, D2]) of separate fp32 tensors standing for their
+        concatenation along the feature axis -- the early-fusion torch.cat of utils/load_datasets_precomputed.py:158-161 -- which
+        is then never materialised: the kernels read both parts.  -> (x1, x2 or None, B, L, D1 + D2)"""
+        if isinstance(xs, (tuple, list)):
+            x1, x2 = xs
+            if x1.shape[:2] != x2.shape[:2]:
+                raise ValueError(f'K-split input parts disagree: {tuple(x1.shape)} vs {tuple(x2.shape)}')
+            if x1.shape[2] % 4 or x2.shape[2] % 4:
+                raise ValueError('K-split input parts must have widths that are multiples of 4')
+            return x1, x2, x1.shape[0], x1.shape[1], x1.shape[2] + x2.shape[2]
+        return xs, None, xs.shape[0], xs.shape[1], xs.shape[2]
+
+    @staticmethod
     def _prep_lengths(lengths, B, L, device):
         if lengths is None:
             return torch.full((B,), L, dtype=torch.int32, device=device)
@@ -435,8 +449,8 @@ class Transformer_segmenter(_TaggerBase):
     # ---- native forward / backward ------------------------------------------------------------------
     def _forward_native(self, xs, lengths_i32, want_grad_state=True, pack=None):
         """pack = {'row_src', 'row0', 'n'} (see _pack_plan): activations hold only the valid sentences."""
+        xs, xs2, B, Lq, D = self._split_input(xs)
         dt, dev = self.compute_dtype, xs.device
-        B, Lq, D = xs.shape
         if D != self.embedding_dim:
             raise ValueError(f'expected input dim {self.embedding_dim}, got {D}')
         if Lq + 2 > self.max_pos:
@@ -447,6 +461,7 @@ class Transformer_segmenter(_TaggerBase):
         wf = self._weights()                  # compute-dtype mirror (GEMM operands)
         pf = self._flat                       # fp32 masters (biases, LayerNorm, embeddings, head)
         x = xs.contiguous().to(torch.float32)
+        x2 = xs2.contiguous().to(torch.float32) if xs2 is not None else None
         e = 'model.model.embeddings.'
         st = {'B': B, 'L': Lq, 'N': N, 'lengths': lengths_i32, 'layers': [], 'pack': pack}
         h = ws.get('h0', N, D, dt, dev)
@@ -455,7 +470,7 @@ class Transformer_segmenter(_TaggerBase):
         rstd0 = ws.get('rstd0', N, 1, torch.float32, dev)
         ops.embed_layernorm_fwd(x, lay.view(pf, e + 'position_embeddings.weight'), 2,
                                 lay.view(pf, e + 'token_type_embeddings.weight')[0], lay.view(pf, e + 'LayerNorm.weight'),
-                                lay.view(pf, e + 'LayerNorm.bias'), self.ln_eps, h, pre0, mean0, rstd0, row_src=row_src)
+                                lay.view(pf, e + 'LayerNorm.bias'), self.ln_eps, h, pre0, mean0, rstd0, row_src=row_src, x2=x2)
         st.update(pre0=pre0, mean0=mean0, rstd0=rstd0)
         pdrop = self.dropout_in if self.training else 0.0          # nn.Dropout: training mode only
         st['pdrop'] = pdrop
@@ -576,8 +591,8 @@ class Transformer_segmenter(_TaggerBase):
         """Native forward(+backward): returns (loss 0-d fp32 tensor, scores [B,L,n_out] -- or [n_valid, n_out] when the batch
         was packed, see _pack_plan); gradients land in grad_flat."""
         L.require_gpu()
-        dev = xs.device
-        B, Lq, _ = xs.shape
+        x1, _, B, Lq, _ = self._split_input(xs)
+        dev = x1.device
         li32 = self._prep_lengths(lengths, B, Lq, dev)
         pack = self._pack_plan(lengths, B, Lq, dev)
         st = self._forward_native(xs, li32, pack=pack)
@@ -599,15 +614,15 @@ class Transformer_segmenter(_TaggerBase):
 
     def encode(self, xs, lengths):
         """Encoder output [B, L, D] (``Longformer_Local_Attention.forward``, RestrictedTransformerLayer.py:118-133)."""
-        B, Lq, _ = xs.shape
-        st = self._forward_native(xs, self._prep_lengths(lengths, B, Lq, xs.device))
+        x1, _, B, Lq, _ = self._split_input(xs)
+        st = self._forward_native(xs, self._prep_lengths(lengths, B, Lq, x1.device))
         return st['hidden'].view(B, Lq, -1).to(torch.float32)
 
     def forward(self, xs, lenghts, threshold=0.4):
         """models/CRF.py:597-610 -> (scores [B,L,n_out], list of per-document bool lists)."""
         L.require_gpu()
-        B, Lq, _ = xs.shape
-        li32 = self._prep_lengths(lenghts, B, Lq, xs.device)
+        x1, _, B, Lq, _ = self._split_input(xs)
+        li32 = self._prep_lengths(lenghts, B, Lq, x1.device)
         with torch.no_grad():
             st = self._forward_native(xs, li32)
             scores = st['scores'].clone()

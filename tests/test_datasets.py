@@ -5,6 +5,7 @@ import os
 import pickle
 
 import numpy as np
+import pytest
 import torch
 
 from tests import helpers as H
@@ -83,3 +84,27 @@ def test_loader_feeds_the_collater(tmp_path):
     lens = batch['src_lengths'].tolist()
     assert batch['src_tokens'].shape == (len(train), max(lens), 10)
     assert sorted(lens) == sorted(t[0].shape[0] for t in train)
+
+
+def test_split_modalities_keeps_the_two_directories_apart(tmp_path):
+    """K-split loading: same documents, labels and order as the concatenating loader (pinned by g12), but the text and audio
+    matrices stay separate; the collater emits them as src_tokens / src_tokens2 and their concat equals the fused batch."""
+    from multimodaltopicsegmentation_amd import AudioPortionDataset, load_dataset_from_precomputed, second_input_of
+    g = H.load('g12_loader')
+    da, db, fresh_labs, time_file, split_file = _write_corpus(g, str(tmp_path))
+    fused = load_dataset_from_precomputed(da + '+' + db, fresh_labs(), split=split_file)[0]
+    parts = load_dataset_from_precomputed(da + '+' + db, fresh_labs(), split=split_file, split_modalities=True)[0]
+    for fa, pa in zip(fused, parts):
+        assert [it[2] for it in fa] == [it[2] for it in pa]
+        for f, p in zip(fa, pa):
+            assert len(p) == 4 and p[1] == f[1]
+            assert torch.equal(torch.cat((p[0], p[3]), dim=-1), f[0])
+    train = parts[0]
+    ds = AudioPortionDataset(train, {'0': 0, '1': 1}, CRF=False, truncate=False, second_input=second_input_of(train))
+    b = ds.collater([ds[i] for i in range(len(ds))])
+    dsf = AudioPortionDataset(fused[0], {'0': 0, '1': 1}, CRF=False, truncate=False)
+    bf = dsf.collater([dsf[i] for i in range(len(dsf))])
+    assert torch.equal(torch.cat((b['src_tokens'], b['src_tokens2']), dim=-1), bf['src_tokens'])
+    assert torch.equal(b['tgt_tokens'], bf['tgt_tokens']) and torch.equal(b['src_lengths'], bf['src_lengths'])
+    with pytest.raises(ValueError):
+        load_dataset_from_precomputed(da, fresh_labs(), split=split_file, split_modalities=True)

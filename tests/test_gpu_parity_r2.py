@@ -353,3 +353,40 @@ def test_bf16_mirror_follows_load_state_dict_after_a_forward(arch):
     a.load_state_dict(b.state_dict())           # on-device load AFTER a forward
     sa2, _ = a.model(x, lengths)
     assert torch.equal(sa2, sb)
+
+
+# ------------------------------------------------------------------------------------------------ f3: K-split input (no concat materialised)
+@pytest.mark.parametrize('arch', ['Transformer', 'BiLSTM', 'biLSTMCRF'])
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_ksplit_pair_equals_the_concatenated_batch(arch, dtype):
+    """TextSegmenter(ksplit=True) on a batch that carries the text and audio embeddings as two tensors (src_tokens, src_tokens2)
+    must give BITWISE the loss, gradients, scores and boundaries of the same model on their concatenation: the kernels read the
+    two parts in place of one matrix (mts_embed_layernorm_fwd2 / mts_cast_concat), the arithmetic is unchanged."""
+    from multimodaltopicsegmentation_amd import TextSegmenter
+    D1, D2, B, Lq = 96, 160, 4, 37
+    g = torch.Generator().manual_seed(31)
+    x1, x2 = torch.randn(B, Lq, D1, generator=g), torch.randn(B, Lq, D2, generator=g)
+    lengths = torch.tensor([37, 20, 1, 9])
+    pad = 0.0 if arch == 'biLSTMCRF' else -1.0
+    y = torch.full((B, Lq), pad)
+    for b, n in enumerate(lengths.tolist()):
+        x1[b, n:] = 0.0
+        x2[b, n:] = 0.0
+        y[b, :n] = (torch.rand(n, generator=g) < 0.25).float()
+    kw = dict(num_layers=2, architecture=arch, loss_fn='FocalLoss', nheads=4, attention_window=8, compute_dtype=dtype)
+    torch.manual_seed(3)
+    a = TextSegmenter(2, D1 + D2, 32, ksplit=True, **kw).to(DEV)
+    torch.manual_seed(3)
+    b_ = TextSegmenter(2, D1 + D2, 32, **kw).to(DEV)
+    b_.load_state_dict(a.state_dict())
+    split = {'src_tokens': x1.to(DEV), 'src_tokens2': x2.to(DEV), 'tgt_tokens': y.to(DEV), 'src_lengths': lengths}
+    fused = {'src_tokens': torch.cat((x1, x2), dim=-1).to(DEV), 'src_tokens2': None, 'tgt_tokens': y.to(DEV), 'src_lengths': lengths}
+    la = a.training_step(split, 0)
+    la.backward()
+    lb = b_.training_step(fused, 0)
+    lb.backward()
+    assert la.item() == lb.item()
+    for (n, p), (_, q) in zip(a.named_parameters(), b_.named_parameters()):
+        assert torch.equal(p.grad, q.grad), n
+    ta, tb = a.predict_step(split, 0), b_.predict_step(fused, 0)
+    assert ta == tb
