@@ -379,6 +379,121 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs a, const S
 }
 
 // ------------------------------------------------------------------------------------------------
+// fp32 on the matrix cores: v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate; exact fp32 -- per output element the same
+// k-ordered fma chain as the VALU kernel above, so parity mode keeps its bars; 64 FLOP/clk/SIMD = the fp32 vector rate, but one
+// instruction per 16x16x4 block instead of 1024 v_fma lane-operations).  128x128x16 tile, 4 waves x (64x64 = 4x4 MFMA tiles),
+// operands staged through registers (arbitrary strides, 16-byte loads along whichever of m / k is contiguous) into k-major LDS
+// rows of 128 + 16 floats (the 4 k-rows a wave-instruction reads then sit 16 banks apart: conflict-free ds_read_b32).
+// The accumulator is computed transposed (B fragment as the first operand) so that a lane owns 4 consecutive columns of one row.
+// ------------------------------------------------------------------------------------------------
+#define F32_BM 128
+#define F32_BK 16
+#define F32_PITCH 144
+
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs a, const StrideArgs s) {
+  __shared__ float As[2][F32_BK][F32_PITCH];
+  __shared__ float Bs[2][F32_BK][F32_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int ntn = (a.N + F32_BM - 1) / F32_BM;
+  const int bm0 = (blockIdx.x / ntn) * F32_BM, bn0 = (blockIdx.x % ntn) * F32_BM;
+  const float* __restrict__ A = reinterpret_cast<const float*>(a.A);
+  const float* __restrict__ B = reinterpret_cast<const float*>(a.B);
+  // operand X (rows r of the tile, k): element (r, k) at X[(r0 + r) * sr + (k0 + k) * sk]; one of sr / sk is 1
+  const bool a_kc = (s.sak == 1), b_kc = (s.sbk == 1);
+  const bool a_vec = (((uintptr_t)A & 15) == 0) && ((a_kc ? s.sam : s.sak) % 4 == 0);
+  const bool b_vec = (((uintptr_t)B & 15) == 0) && ((b_kc ? s.sbn : s.sbk) % 4 == 0);
+  float4 ra[2], rb[2];
+
+  // 128 x 16 floats per operand and K-tile = 512 float4: two per thread.  k-contiguous: float4 = 4 consecutive k of one row
+  // (f = tid + 256 i: row f >> 2, k group f & 3); row-contiguous: 4 consecutive rows of one k (k = f >> 5, row group f & 31).
+  auto load_op = [&](const float* __restrict__ X, long sr, long sk, bool kc, bool vec, int r0, int rdim, int k0, float4 (&r)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int f = tid + 256 * i;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (kc) {
+        const int row = r0 + (f >> 2), k = k0 + (f & 3) * 4;
+        if (row < rdim) {
+          const float* p = X + (long)row * sr + k;
+          if (vec && k + 3 < a.K) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+          else for (int j = 0; j < 4; ++j) if (k + j < a.K) v[j] = p[j];
+        }
+      } else {
+        const int k = k0 + (f >> 5), row = r0 + (f & 31) * 4;
+        if (k < a.K) {
+          const float* p = X + (long)k * sk + row;
+          if (vec && row + 3 < rdim) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+          else for (int j = 0; j < 4; ++j) if (row + j < rdim) v[j] = p[j];
+        }
+      }
+      r[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  };
+  auto store_op = [&](float (&S)[F32_BK][F32_PITCH], bool kc, const float4 (&r)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int f = tid + 256 * i;
+      if (kc) {
+        const int row = f >> 2, k = (f & 3) * 4;
+        S[k][row] = r[i].x; S[k + 1][row] = r[i].y; S[k + 2][row] = r[i].z; S[k + 3][row] = r[i].w;
+      } else {
+        *reinterpret_cast<float4*>(&S[f >> 5][(f & 31) * 4]) = r[i];
+      }
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (a.K + F32_BK - 1) / F32_BK;
+  load_op(A, s.sam, s.sak, a_kc, a_vec, bm0, a.M, 0, ra);
+  load_op(B, s.sbn, s.sbk, b_kc, b_vec, bn0, a.N, 0, rb);
+  store_op(As[0], a_kc, ra);
+  store_op(Bs[0], b_kc, rb);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) {                                  // the next K-tile's global loads fly under this tile's MFMAs
+      load_op(A, s.sam, s.sak, a_kc, a_vec, bm0, a.M, (kt + 1) * F32_BK, ra);
+      load_op(B, s.sbn, s.sbk, b_kc, b_vec, bn0, a.N, (kt + 1) * F32_BK, rb);
+    }
+#pragma unroll
+    for (int ks = 0; ks < F32_BK / 4; ++ks) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        av[i] = As[buf][ks * 4 + g][wm * 64 + i * 16 + r16];
+        bv[i] = Bs[buf][ks * 4 + g][wn * 64 + i * 16 + r16];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[j], av[i], acc[i][j], 0, 0, 0);   // C^T tile
+    }
+    if (kt + 1 < nk) {
+      store_op(As[buf ^ 1], a_kc, ra);
+      store_op(Bs[buf ^ 1], b_kc, rb);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = bm0 + wm * 64 + i * 16 + r16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = bn0 + wn * 64 + j * 16 + 4 * g;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      epilogue4<float, float>(a, m, n, v, true);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // column sums (bias gradients): two deterministic stages
 // ------------------------------------------------------------------------------------------------
 #define COLSUM_RS 128
@@ -562,6 +677,7 @@ extern "C" int mts_gemm_last_plan(int* tile, int* splits) {
 }
 
 void mts_band_set_mfma(int on);   // band_attn.hip
+static int g_f32_mfma = 1;                   // fp32 (parity mode) GEMM on v_mfma_f32_16x16x4_f32; 0 = VALU kernel
 static int g_gemm_variant = 0;               // A/B switch of the big-tile kernels (GemmArgs::variant)
 void mts_lstm_pair_set_spin_limit(int n);   // lstm_pair.hip
 void mts_lstm_pair_set_max_pairs(int n);
@@ -574,6 +690,7 @@ extern "C" int mts_set_option(const char* key, int value) {
   if (!strcmp(key, "gemm_chain")) { g_chain = value; return MTS_OK; }
   if (!strcmp(key, "gemm_deep")) { g_gemm_deep = value; return MTS_OK; }
   if (!strcmp(key, "gemm_variant")) { g_gemm_variant = value; return MTS_OK; }
+  if (!strcmp(key, "gemm_f32_mfma")) { g_f32_mfma = value; return MTS_OK; }
   if (!strcmp(key, "band_mfma")) { mts_band_set_mfma(value); return MTS_OK; }
   if (!strcmp(key, "lstm_pair_spin_limit")) { mts_lstm_pair_set_spin_limit(value); return MTS_OK; }
   if (!strcmp(key, "lstm_pair_max_pairs")) { mts_lstm_pair_set_max_pairs(value); return MTS_OK; }
@@ -639,7 +756,9 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
     else { s.sam = 1; s.sak = lda; s.sbn = 1; s.sbk = ldb; }
     MTS_CHECK_ARG(ldc % 4 == 0 && ((uintptr_t)C % 16) == 0, "mts_gemm(f32): C must be 16-byte aligned with ldc %% 4 == 0");
     MTS_CHECK_ARG(!(epilogue & MTS_EPI_RESIDUAL) || (ldr % 4 == 0), "mts_gemm(f32): ldr %% 4");
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3(ceil_div(M, 64) * ceil_div(N, 64)), dim3(256), 0, st, a, s);
+    // "gemm_f32_mfma" = 1 (default): exact-fp32 matrix-core kernel; 0: the VALU kernel (A/B, and the form the round-1 fixtures ran on)
+    if (g_f32_mfma) hipLaunchKernelGGL(gemm_f32_mfma_kernel, dim3(ceil_div(M, F32_BM) * ceil_div(N, F32_BM)), dim3(256), 0, st, a, s);
+    else hipLaunchKernelGGL(gemm_f32_kernel, dim3(ceil_div(M, 64) * ceil_div(N, 64)), dim3(256), 0, st, a, s);
     MTS_LAUNCH_CHECK("mts_gemm(f32)");
     return MTS_OK;
   }
