@@ -456,8 +456,7 @@ def test_adam_and_sgd_match_torch(ops):
 @pytest.mark.parametrize('M,N,K', [(128, 128, 64), (200, 136, 72), (130, 260, 1030), (16, 8, 8), (1000, 264, 2048)])
 def test_gemm_f32_matrix_core_kernel_matches_the_valu_kernel(ops, layout, M, N, K):
     """Parity mode's GEMM runs on v_mfma_f32_16x16x4_f32 (exact fp32): against fp64 math to 2e-6 * sqrt(K) relative, and against the
-    VALU kernel ("gemm_f32_mfma" = 0, same k-ordered fma chain per output element) to 1e-6 of the largest entry -- bitwise equality
-    is reported, not required (it holds if the instruction's four products are chained in k order)."""
+    VALU kernel ("gemm_f32_mfma" = 0, the same k-ordered fma chain per output element) BIT FOR BIT."""
     from multimodaltopicsegmentation_amd import _lib as L
     g = torch.Generator().manual_seed(M + N + K)
     shp = {'NT': ((M, K), (N, K)), 'NN': ((M, K), (K, N)), 'TN': ((K, M), (K, N)), 'TT': ((K, M), (N, K))}[layout]
@@ -477,5 +476,5 @@ def test_gemm_f32_matrix_core_kernel_matches_the_valu_kernel(ops, layout, M, N, 
         L.lib.mts_set_option(b'gemm_f32_mfma', 1)
     scale = float(ref.abs().max())
     assert float((outs[1].double() - ref).abs().max()) < 2e-6 * (K ** 0.5) * scale
-    assert float((outs[1] - outs[0]).abs().max()) <= 1e-6 * scale
-    print(f'f32 mfma vs valu {layout} {M}x{N}x{K}: bitwise equal = {torch.equal(outs[1], outs[0])}')
+    # measured on MI355X: the instruction chains its four products in k order, so the two kernels agree bit for bit
+    assert torch.equal(outs[1], outs[0])
