@@ -8,7 +8,7 @@
 //
 // 256x224x64 bf16 MFMA GEMM, FOUR waves per workgroup (one per SIMD), wave tile 128 x 112, fragments double-buffered in registers.
 //
-// Why a second form of gemm224.hip.  rocprofv3 counters on the BASELINE forward projection (profiles/r02_gemm_pmc.txt) put the
+// Why a second form of gemm224.hip.  rocprofv3 counters on the BASELINE forward projection (profiles/r02_gemm_pmc_vs_vendor.txt) put the
 // 8-wave kernel's matrix cores at ~51 % busy against ~70 % for the vendor library's 256x256x64 kernel (four waves, one per SIMD):
 // its two waves per SIMD run the same program in lockstep, so both wait for LDS behind every workgroup barrier and both want the
 // matrix pipe at the same moment.  Here a wave owns its SIMD and hides LDS latency INSIDE its own instruction stream:
