@@ -678,6 +678,7 @@ extern "C" int mts_gemm_last_plan(int* tile, int* splits) {
 
 void mts_band_set_mfma(int on);   // band_attn.hip
 static int g_f32_mfma = 1;                   // fp32 (parity mode) GEMM on v_mfma_f32_16x16x4_f32; 0 = VALU kernel
+static int g_big_min_k = 256;                // smallest K the big-tile kernels are considered for ("gemm_big_min_k")
 static int g_gemm_variant = 0;               // A/B switch of the big-tile kernels (GemmArgs::variant)
 void mts_lstm_pair_set_spin_limit(int n);   // lstm_pair.hip
 void mts_lstm_pair_set_max_pairs(int n);
@@ -690,6 +691,7 @@ extern "C" int mts_set_option(const char* key, int value) {
   if (!strcmp(key, "gemm_chain")) { g_chain = value; return MTS_OK; }
   if (!strcmp(key, "gemm_deep")) { g_gemm_deep = value; return MTS_OK; }
   if (!strcmp(key, "gemm_variant")) { g_gemm_variant = value; return MTS_OK; }
+  if (!strcmp(key, "gemm_big_min_k")) { g_big_min_k = value; return MTS_OK; }
   if (!strcmp(key, "gemm_f32_mfma")) { g_f32_mfma = value; return MTS_OK; }
   if (!strcmp(key, "band_mfma")) { mts_band_set_mfma(value); return MTS_OK; }
   if (!strcmp(key, "lstm_pair_spin_limit")) { mts_lstm_pair_set_spin_limit(value); return MTS_OK; }
@@ -787,7 +789,7 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
   const bool can_split = (c_dtype == MTS_F32 && plain == 0 && workspace && N % 4 == 0 && K >= 2048);
   // (until the transposed LDS reads became inline asm -- gemm_common.h -- the big tiles' TN form was slower than the 128
   // kernel: one workgroup per CU had nothing to hide the exposed DMA wait behind; now it is the fastest weight-gradient form)
-  const bool can256 = (K % BK == 0) && K >= 512 && M >= 8 && N >= 8 && tile_mode != 128;
+  const bool can256 = (K % BK == 0) && K >= g_big_min_k && M >= 8 && N >= 8 && tile_mode != 128;
   const double bw = 3500.0;     // slab MB per us
   double best = 1e30;
   int splits = 1;

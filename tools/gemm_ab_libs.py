@@ -13,18 +13,23 @@ import torch
 vp, i32, f32, u32, sz = C.c_void_p, C.c_int, C.c_float, C.c_uint, C.c_size_t
 libs = []
 for spec in [a for a in sys.argv[1:] if not a.startswith('--')]:
-    path, _, var = spec.partition('@')          # lib.so@5 = that library with mts_set_option("gemm_variant", 5)
+    path, _, var = spec.partition('@')          # lib.so@5 = that library with mts_set_option("gemm_variant", 5); lib.so@k256: gemm_big_min_k
     lib = C.CDLL(path)
     lib.mts_set_option.argtypes = [C.c_char_p, i32]
     lib.mts_last_error.restype = C.c_char_p
     lib.mts_gemm.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp, i32, vp, i32, u32, f32, i32, vp, sz]
-    libs.append((path.split('/')[-1] + ('@' + var if var else ''), lib, int(var) if var else None))
+    libs.append((path.split('/')[-1] + ('@' + var if var else ''), lib, var or None))
 blas = '--blas' in sys.argv
 dev = 'cuda'
 # (label, layout, M, N, K, epilogue flags)   flags: 1 bias, 2 residual, 8 column scale
 SHAPES = [('fwd QKV', 0, 16384, 5376, 1792, 1 | 8), ('fwd out-proj', 0, 16384, 1792, 1792, 1 | 2),
           ('dgrad QKV', 1, 16384, 1792, 5376, 2), ('dgrad out-proj', 1, 16384, 1792, 1792, 0),
-          ('wgrad QKV', 2, 5376, 1792, 16384, 0), ('wgrad out-proj', 2, 1792, 1792, 16384, 0)]
+          ('wgrad QKV', 2, 5376, 1792, 16384, 0), ('wgrad out-proj', 2, 1792, 1792, 16384, 0),
+          ('fwd FFN down', 0, 16384, 1792, 256, 1 | 2), ('dgrad FFN up', 1, 16384, 1792, 256, 2),
+          ('fwd FFN up', 0, 16384, 256, 1792, 1), ('dgrad FFN down', 1, 16384, 256, 1792, 0),
+          ('wgrad FFN up', 2, 256, 1792, 16384, 0), ('wgrad FFN down', 2, 1792, 256, 16384, 0)]
+if '--ffn' in sys.argv:
+    SHAPES = SHAPES[6:]
 g = torch.Generator(device=dev).manual_seed(1)
 ws = torch.empty(16 * 5376 * 1792 * 4, dtype=torch.uint8, device=dev)
 for label, lay, M, N, K, epi in SHAPES:
@@ -43,7 +48,11 @@ for label, lay, M, N, K, epi in SHAPES:
     def make(lib, var):
         def run():
             if var is not None:
-                lib.mts_set_option(b'gemm_variant', var)
+                if var.startswith('k'):
+                    lib.mts_set_option(b'gemm_big_min_k', int(var[1:]))
+                else:
+                    lib.mts_set_option(b'gemm_big_min_k', 512)
+                    lib.mts_set_option(b'gemm_variant', int(var))
             rc = lib.mts_gemm(st, 1, 0 if lay == 2 else 1, lay, M, N, K, A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), out.data_ptr(), N,
                               bias.data_ptr() if epi & 1 else None, res.data_ptr() if epi & 2 else None, N, None, 0, epi, 0.0668, 1792,
                               ws.data_ptr() if lay == 2 else None, ws.numel() if lay == 2 else 0)
