@@ -154,6 +154,21 @@ int mts_gelu_bwd(void* stream, int dtype, size_t n, const void* u, void* dy);
 int mts_relu_bwd(void* stream, int dtype, size_t n, const void* u, void* dy);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused feed-forward block (hidden width F = 256, D a multiple of 256, bf16): LongformerIntermediate + LongformerOutput.dense +
+ * residual (modeling_longformer.py:1113-1131) in one launch, and the data gradient of the same block in one launch.
+ *   forward : u = a1 W1^T + b1 ; f = gelu_erf(u) (relu != 0: max(u, 0)) ; s2 = f W2^T + b2 + a1
+ *   backward: du = (ds2 W2) * act'(u) ; da1 = du W1 + ds2        (weight / bias gradients: mts_gemm TN, mts_colsum on du)
+ * a1, ds2 [M, D]; w1 [F, D]; w2 [D, F] (bf16 mirrors); b1 [F], b2 [D] fp32; u, f, du [., F]; s2, da1 [., D].  OUTPUT buffers must
+ * have room for ceil(M / 64) * 64 rows (rows past M are written, not masked).  Bitwise the results of the two-GEMM path.
+ * mts_ffn_supported: 1 when the fused block covers (dtype, M, D, F), else the caller uses mts_gemm.
+ * ------------------------------------------------------------------------------------------- */
+int mts_ffn_supported(int dtype, int M, int D, int F);
+int mts_ffn_fwd(void* stream, int M, int D, int F, const void* a1, const void* w1, const float* b1, const void* w2, const float* b2,
+                int relu, void* u, void* f, void* s2);
+int mts_ffn_bwd_data(void* stream, int M, int D, int F, const void* ds2, const void* w1, const void* w2, const void* u, int relu,
+                     void* du, void* da1);
+
+/* ---------------------------------------------------------------------------------------------
  * PACKED BATCHES (training path; the reference pads every Transformer batch to 3600 sentences, train_fit.py:104-106,
  * and runs all of them through the encoder).  Activations may hold only the valid sentences, document after document:
  * n_rows = sum of lengths; `row_src[r]` = b*L + i names the sentence of the padded batch that packed row r holds

@@ -48,6 +48,9 @@ SIGNATURES = {
     'mts_dropout_bwd': (_i, [_vp, _i, _sz, _vp, _vp, _vp, _f]),
     'mts_gelu_bwd': (_i, [_vp, _i, _sz, _vp, _vp]),
     'mts_relu_bwd': (_i, [_vp, _i, _sz, _vp, _vp]),
+    'mts_ffn_supported': (_i, [_i, _i, _i, _i]),
+    'mts_ffn_fwd': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    'mts_ffn_bwd_data': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     'mts_band_slots': (_i, [_i]),
     'mts_band_attn_fwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, C.c_uint64]),
     'mts_band_attn_bwd_workspace': (_sz, [_i, _i, _i]),

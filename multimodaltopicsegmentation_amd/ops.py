@@ -187,6 +187,23 @@ def relu_bwd(u, dy):
     check(lib.mts_relu_bwd(stream_ptr(), dtype_code(u.dtype), u.numel(), ptr(u), ptr(dy)))
 
 
+def ffn_supported(dtype, M, D, F):
+    return bool(lib.mts_ffn_supported(dtype_code(dtype), M, D, F)) if dtype in (torch.float32, torch.bfloat16) else False
+
+
+def ffn_fwd(a1, w1, b1, w2, b2, u, f, s2, relu=False):
+    """Fused feed-forward block (F = 256): u, f [M, F] and s2 [M, D] are views of buffers with room for ceil(M / 64) * 64 rows."""
+    M, D = a1.shape
+    with _timed(('ffn_fwd', M, D, w1.shape[0])):
+        check(lib.mts_ffn_fwd(stream_ptr(), M, D, w1.shape[0], ptr(a1), ptr(w1), ptr(b1), ptr(w2), ptr(b2), int(relu), ptr(u), ptr(f), ptr(s2)))
+
+
+def ffn_bwd_data(ds2, w1, w2, u, du, da1, relu=False):
+    M, D = ds2.shape
+    with _timed(('ffn_bwd', M, D, w1.shape[0])):
+        check(lib.mts_ffn_bwd_data(stream_ptr(), M, D, w1.shape[0], ptr(ds2), ptr(w1), ptr(w2), ptr(u), int(relu), ptr(du), ptr(da1)))
+
+
 def band_slots(radius):
     return lib.mts_band_slots(radius)
 

@@ -182,6 +182,8 @@ class _TaggerBase(FlatModule):
     # (a span of adjacent tensors; q/k/v are three tensors in the HF layout and one packed in_proj in the legacy one).
     # Needs self.embedding_dim, self.nheads, self._ffp (FFN width as stored), self.ln_eps, self.ffn_act ('gelu' | 'relu').
     ffn_act = 'gelu'
+    fuse_ffn = os.environ.get('MTS_FUSE_FFN', '1') != '0'    # one launch per direction for the feed-forward block where mts_ffn_* covers it
+                                                              # (bf16, F = 256, d a multiple of 256, no hidden dropout); bitwise the same results
 
     def _lt(self, flat, names, key, rows, cols):
         first, last = names[key]
@@ -218,13 +220,22 @@ class _TaggerBase(FlatModule):
         rstd1 = ws.get(f'rstd1_{tag}', N, 1, torch.float32, dev)
         ops.layernorm_fwd(s1, self._lt(pf, names, 'ln1w', 1, D).view(-1), self._lt(pf, names, 'ln1b', 1, D).view(-1), self.ln_eps,
                           a1, mean1, rstd1)
-        u = ws.get(f'u{tag}', N, F, dt, dev)
-        f = ws.get(f'f{tag}', N, F, dt, dev)
+        # the fused block writes whole 64-row tiles: its outputs live in buffers with ceil(N / 64) * 64 rows (rows past N are scratch)
+        Np = round_up(N, 64)
+        u = ws.get(f'u{tag}', Np, F, dt, dev)[:N]
+        f = ws.get(f'f{tag}', Np, F, dt, dev)[:N]
         relu = self.ffn_act == 'relu'
-        ops.linear_fwd(a1, self._lt(wf, names, 'w1', F, D), self._lt(pf, names, 'b1', 1, F).view(-1), f, gelu=not relu, relu=relu, aux=u)
-        s2 = ws.get(f's2_{tag}', N, D, dt, dev)
+        s2 = ws.get(f's2_{tag}', Np, D, dt, dev)[:N]
         w2, b2 = self._lt(wf, names, 'w2', D, F), self._lt(pf, names, 'b2', 1, D).view(-1)
-        if pdrop:                                                  # :1128-1131
+        fused = self.fuse_ffn and not pdrop and ops.ffn_supported(dt, N, D, F)
+        w1, b1 = self._lt(wf, names, 'w1', F, D), self._lt(pf, names, 'b1', 1, F).view(-1)
+        if fused:                                                  # up-projection, activation, down-projection, residual: one launch
+            ops.ffn_fwd(a1, w1, b1, w2, b2, u, f, s2, relu=relu)
+        else:
+            ops.linear_fwd(a1, w1, b1, f, gelu=not relu, relu=relu, aux=u)
+        if fused:
+            pass
+        elif pdrop:                                                # :1128-1131
             tmp = ws.get('droptmp', N, D, dt, dev)
             m2 = ws.get(f'dropmask2_{tag}', N, D, torch.uint8, dev)
             ops.linear_fwd(f, w2, b2, tmp)
@@ -238,7 +249,7 @@ class _TaggerBase(FlatModule):
                           hout, mean2, rstd2, head_w=head[0] if head else None, head_b=head[1] if head else None,
                           scores=head[2] if head else None)
         return dict(hin=h, qkv=qkv, ctx=ctx, probs=probs, s1=s1, a1=a1, mean1=mean1, rstd1=rstd1, u=u, f=f, s2=s2, hout=hout,
-                    mean2=mean2, rstd2=rstd2, radius=radius, slots=slots, m1=m1, m2=m2, pattn=pattn, aseed=aseed)
+                    mean2=mean2, rstd2=rstd2, radius=radius, slots=slots, m1=m1, m2=m2, pattn=pattn, aseed=aseed, fused_ffn=fused)
 
     def _band_layer_bwd(self, names, S, dh, lengths_i32, B, Lq, N, pdrop, row0, wgrad, tail_end, head=None, slot=0):
         """Gradients of one layer into grad_flat; returns d(layer input).  dh: gradient wrt the layer output (None when only the
@@ -262,18 +273,26 @@ class _TaggerBase(FlatModule):
             ds2d = ws.get('ds2d', N, D, dt, dev)               # gradient of the dense branch; the residual branch keeps ds2
             ops.dropout_bwd(ds2, ds2d, S['m2'], pdrop)
             ops.colsum(ds2d, Gv('b2', 1, D).view(-1))
-        wgrad(ds2d, S['f'], Gv('w2', D, F))
-        du = ws.get('du', N, F, dt, dev)
-        ops.linear_dgrad(ds2d, self._lt(wf, names, 'w2', D, F), du)
-        if self.ffn_act == 'relu':
-            ops.relu_bwd(S['u'], du)
+        Np = round_up(N, 64)
+        du = ws.get('du', Np, F, dt, dev)[:N]
+        da1 = ws.get('da1', Np, D, dt, dev)[:N]
+        if S.get('fused_ffn') and not pdrop:
+            # du = (ds2 W2) * act'(u) and da1 = du W1 + ds2 in one launch (the intermediate stays in LDS); weight gradients as before
+            ops.ffn_bwd_data(ds2, self._lt(wf, names, 'w1', F, D), self._lt(wf, names, 'w2', D, F), S['u'], du, da1, relu=self.ffn_act == 'relu')
+            wgrad(ds2, S['f'], Gv('w2', D, F))
+            ops.colsum(du, Gv('b1', 1, F).view(-1))
+            wgrad(du, S['a1'], Gv('w1', F, D))
         else:
-            ops.gelu_bwd(S['u'], du)
-        ops.colsum(du, Gv('b1', 1, F).view(-1))
-        # FFN up:  u = a1 W1^T + b1 ;  da1 = ds2 (residual) + du W1
-        wgrad(du, S['a1'], Gv('w1', F, D))
-        da1 = ws.get('da1', N, D, dt, dev)
-        ops.linear_dgrad(du, self._lt(wf, names, 'w1', F, D), da1, residual=ds2)
+            wgrad(ds2d, S['f'], Gv('w2', D, F))
+            ops.linear_dgrad(ds2d, self._lt(wf, names, 'w2', D, F), du)
+            if self.ffn_act == 'relu':
+                ops.relu_bwd(S['u'], du)
+            else:
+                ops.gelu_bwd(S['u'], du)
+            ops.colsum(du, Gv('b1', 1, F).view(-1))
+            # FFN up:  u = a1 W1^T + b1 ;  da1 = ds2 (residual) + du W1
+            wgrad(du, S['a1'], Gv('w1', F, D))
+            ops.linear_dgrad(du, self._lt(wf, names, 'w1', F, D), da1, residual=ds2)
         ds1 = ws.get('ds1', N, D, dt, dev)
         ops.layernorm_bwd(S['s1'], da1, self._lt(pf, names, 'ln1w', 1, D).view(-1), S['mean1'], S['rstd1'], ds1,
                           Gv('ln1w', 1, D).view(-1), Gv('ln1b', 1, D).view(-1), dxsum=Gv('bo', 1, D).view(-1))
