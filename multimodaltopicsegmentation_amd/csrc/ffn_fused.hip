@@ -89,54 +89,106 @@ __device__ __forceinline__ frag_raw ff_frag_strided(const char* tile, int kbase,
   return f;
 }
 
+#define FF_CWAVES 8                     // compute waves: 2 (M: 32 rows) x 4 (N: 64 columns)
+#define FF_LWAVES 4                     // copy waves
+#define FF_THREADS ((FF_CWAVES + FF_LWAVES) * 64)
+
 template <bool BWD>
-__global__ __launch_bounds__(512, 2) void ffn_fused_kernel(const FfnArgs a) {
+__global__ __launch_bounds__(FF_THREADS) void ffn_fused_kernel(const FfnArgs a) {
   constexpr bool WKM = !BWD;            // weight tiles K-major (forward) or strided (backward)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* fimg = smem;
   char* ring = smem + FF_RING;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int r16 = lane & 15, g = lane >> 4;
   const int bm0 = blockIdx.x * FF_BM;
   const int D = a.D, M = a.M;
-  const int nkA = D / 64, nch = D / 256;
-
-  // ---- copies ----------------------------------------------------------------------------------------------------------
-  // phase A stage: 8 X pieces + 32 weight pieces = 40, 5 per wave.  Weight tile: forward rows = the 256 columns of u (K-major,
-  // 32 pieces of 8 rows); backward k-rows of W2 (two strided half images of 128 columns, 16 pieces each).
-  auto dmaA = [&](int kt) {
-#ifdef FFN_DBG_NO_DMA                   // timing experiments only (tools/micro/ffn_variants.sh): results are wrong
-    return;
-#endif
-    char* st = ring + (kt % 3) * FF_A_STAGE;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int q = wave * 5 + i;
-      if (q < 8) ff_piece_kmajor<false>(a.X, D, bm0, M, kt * 64, st, q, lane);
-      else if constexpr (WKM) ff_piece_kmajor<true>(a.Wa, D, 0, FF_F, kt * 64, st + 8192, q - 8, lane);
-      else ff_piece_strided(a.Wa, FF_F, kt * 64, ((q - 8) >> 4) * 128, st + 8192 + ((q - 8) >> 4) * 16384, (q - 8) & 15, lane);
-    }
-  };
-  // phase B stage g = chunk * 4 + kk: second-weight tile for output columns chunk*256 .. +255 and k = kk*64 .. +63; 32 pieces, 4 per wave
-  auto dmaB = [&](int gi) {
-#ifdef FFN_DBG_NO_DMA
-    return;
-#endif
-    char* st = ring + (gi & 3) * FF_B_STAGE;
-    const int c = gi >> 2, kk = gi & 3;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int q = wave * 4 + i;
-      if constexpr (WKM) ff_piece_kmajor<true>(a.Wb, FF_F, c * 256, D, kk * 64, st, q, lane);
-      else ff_piece_strided(a.Wb, D, kk * 64, c * 256 + (q >> 4) * 128, st + (q >> 4) * 16384, q & 15, lane);
-    }
-  };
-
+  const int nkA = D / 64, nch = D / 256, nB = nch * 4;
 #ifdef FFN_STAMPS
   unsigned long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#define FF_STAMPS_OUT() do { if (a.stamps && lane == 0) for (int i_ = 0; i_ < 16; ++i_) a.stamps[((size_t)blockIdx.x * 12 + wave) * 16 + i_] = tacc[i_]; } while (0)
+#else
+#define FF_STAMPS_OUT() do { } while (0)
+#endif
+
+  // ======================================================================================================================
+  // Copy waves (8 .. 11).  Every LDS-DMA of the kernel is issued here and only here: the vector-memory front end of a CU takes one
+  // 1-KiB copy instruction per ~18 cycles, so the 40 (phase A) / 32 (phase B) copies of a step keep it busy for most of the step
+  // -- and the wave that issues them is stalled for as long.  Issued by the compute waves (as in the first version of this kernel)
+  // that stall sat in front of every step's MFMAs: 690 of a step's 1600 cycles.  Here the compute waves never touch the copy
+  // queue; their own loads and stores (epilogues) have their counter to themselves, the copy waves' counter holds copies only.
+  // Both kinds meet at the one workgroup barrier per step: a copy wave arrives after the NEXT step's stage has landed.
+  // ======================================================================================================================
+  if (wave >= FF_CWAVES) {
+    const int lw = wave - FF_CWAVES;
+    // phase A stage: 8 X pieces + 32 weight pieces = 40, 10 per copy wave.  Weight tile: forward rows = the 256 columns of u
+    // (K-major, 32 pieces of 8 rows); backward k-rows of W2 (two strided half images of 128 columns, 16 pieces each).
+    auto dmaA = [&](int kt) {
+      char* st = ring + (kt % 3) * FF_A_STAGE;
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        const int q = lw * 10 + i;
+        if (q < 8) ff_piece_kmajor<false>(a.X, D, bm0, M, kt * 64, st, q, lane);
+        else if constexpr (WKM) ff_piece_kmajor<true>(a.Wa, D, 0, FF_F, kt * 64, st + 8192, q - 8, lane);
+        else ff_piece_strided(a.Wa, FF_F, kt * 64, ((q - 8) >> 4) * 128, st + 8192 + ((q - 8) >> 4) * 16384, (q - 8) & 15, lane);
+      }
+    };
+    // phase B stage gi = chunk * 4 + kk: second-weight tile for output columns chunk*256 .. +255, k = kk*64 .. +63; 32 pieces, 8 each
+    auto dmaB = [&](int gi) {
+      char* st = ring + (gi & 3) * FF_B_STAGE;
+      const int c = gi >> 2, kk = gi & 3;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int q = lw * 8 + i;
+        if constexpr (WKM) ff_piece_kmajor<true>(a.Wb, FF_F, c * 256, D, kk * 64, st, q, lane);
+        else ff_piece_strided(a.Wb, D, kk * 64, c * 256 + (q >> 4) * 128, st + (q >> 4) * 16384, q & 15, lane);
+      }
+    };
+    dmaA(0);
+    if (nkA > 1) { dmaA(1); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }      // K-tile 0 landed
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma clang loop unroll(disable)
+    for (int kt = 0; kt < nkA; ++kt) {
+      // into the stage read during K-tile kt-1 (every compute wave is past that step's barrier)
+      if (kt + 2 < nkA) { dmaA(kt + 2); FSTAMP(0); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }     // all but K-tile kt+2: kt+1 landed
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      FSTAMP(3);
+      __builtin_amdgcn_s_barrier();
+      FSTAMP(4);
+    }
+    // the ring is free (every wave is past the last barrier of phase A): phase B's first three stages, while the compute waves run
+    // phase A's epilogue
+    dmaB(0);
+    dmaB(1);
+    dmaB(2);
+    dmaB(3);                                                                  // nB >= 4 always (D >= 256)
+    FSTAMP(5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // (the compute waves' epilogue takes far longer than these)
+    __builtin_amdgcn_s_barrier();
+    FSTAMP(6);
+#pragma clang loop unroll(disable)
+    for (int gi = 0; gi < nB; ++gi) {
+      // During step gi the compute waves read slot gi & 3 and slots of stages gi+1 .. gi+3 are full or filling: the one free slot
+      // is that of stage gi-1 (everyone is past that step's barrier), and stage gi+3 goes there.  The step's barrier needs stage
+      // gi+1 landed: stages gi+2 and gi+3 (8 copies each from this wave) may still be in flight.
+      if (gi >= 1 && gi + 3 < nB) { dmaB(gi + 3); FSTAMP(8); asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      FSTAMP(11);
+      __builtin_amdgcn_s_barrier();
+      FSTAMP(12);
+    }
+    FF_STAMPS_OUT();
+    return;
+  }
+
+  // ======================================================================================================================
+  // Compute waves (0 .. 7)
+  // ======================================================================================================================
+  const int wm = wave >> 2, wn = wave & 3;
+  const int r16 = lane & 15, g = lane >> 4;
+#ifdef FFN_STAMPS
   int tb = 0;                            // 0: phase A slots 0..4, 8: phase B slots 8..12
 #endif
   f32x4 acc[2][4];
@@ -145,25 +197,28 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(const FfnArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // one K-tile of MFMAs: A fragments from a K-major image (rows wm*32 + i*16 + r16), B fragments from the weight tile
-  auto mma_tile = [&](const char* At, const char* Bt) {
-#ifdef FFN_DBG_NO_MMA
-    return;
-#endif
+  // one K-tile of MFMAs: A fragments from a K-major image (rows wm*32 + i*16 + r16), B fragments from the weight tile.
+  // K-major reads as  lane part (VGPR) + wave part (added once per tile) + immediate offset: kmajor_off(row, chunk) with
+  // row = 16 t + r16 is  t * 2048  +  r16 * 128 + ((chunk ^ key(r16)) << 4), so the tile index t of a fragment is an instruction
+  // immediate and a step needs four address registers instead of one per fragment (which the compiler hoisted out of the loops
+  // for every stage of the ring, then spilled).
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  unsigned lk[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) lk[ks] = lds0 + r16 * 128 + (((ks * 4 + g) ^ ((r16 >> 1) & 7)) << 4);
+  auto mma_tile = [&](int Aoff, int Boff) {                // byte offsets of the two tiles from the start of the LDS
     LFrag<true> fa[2][2];
     LFrag<WKM> fb[4][2];
-#ifdef FFN_DBG_NO_LDSREAD
-    if (a.M < 0)
-#endif
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+      const unsigned ab = lk[ks] + Aoff + wm * 4096, bb = lk[ks] + Boff + wn * 8192;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if constexpr (WKM) lfrag_read<true>(fb[j][ks], Bt, wn * 64 + j * 16 + r16, ks * 4 + g, lane);
-        else fb[j][ks].s = ff_frag_strided(Bt + (wn >> 1) * 16384, ks * 32 + 8 * g, (wn & 1) * 64, j, lane);
+        if constexpr (WKM) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[j][ks].k) : "v"(bb), "n"(j * 2048));
+        else fb[j][ks].s = ff_frag_strided(smem + Boff + (wn >> 1) * 16384, ks * 32 + 8 * g, (wn & 1) * 64, j, lane);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i) lfrag_read<true>(fa[i][ks], At, wm * 32 + i * 16 + r16, ks * 4 + g, lane);
+      for (int i = 0; i < 2; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[i][ks].k) : "v"(ab), "n"(i * 2048));
     }
     lgkm_wait<0>();
     FSTAMP(tb + 1);                      // operand reads landed
@@ -185,13 +240,9 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(const FfnArgs a) {
   };
 
   // =============================== phase A: T[64, 256] = X[64, D] . Wa ====================================================
-  dmaA(0);
-  if (nkA > 1) dmaA(1);
-  // phase A's epilogue operands, requested behind the first copies (waited for at the end of K-tile 0 together with them, long
-  // before their use): backward the saved pre-activations of this lane's 2 x 4 fragments, forward the first bias.  (A load issued
-  // AFTER later copies could only be waited for together with those copies: the compiler does not count LDS-DMA operations.)
+  // phase A's epilogue operands first (needed 28 steps from now): backward the saved pre-activations, forward the first bias
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-  uint4 upre[2][2];                     // [row block i][column half s]: 8 columns wn*64 + s*32 + g*8 .. +7
+  uint4 upre[2][2];                     // [row block i][column half h]: 8 columns wn*64 + h*32 + g*8 .. +7
   float4 b1[2][2];
   if constexpr (BWD) {
 #pragma unroll
@@ -205,135 +256,90 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(const FfnArgs a) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) b1[h][e] = *reinterpret_cast<const float4*>(a.ba + wn * 64 + h * 32 + g * 8 + e * 4);
   }
-  // K-tile 0 landed: everything but K-tile 1's 5 copies and the 4 loads above
-  if (nkA > 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_s_barrier();                            // K-tile 0 landed (the copy waves waited for it)
 #pragma clang loop unroll(disable)
   for (int kt = 0; kt < nkA; ++kt) {
-    if (kt + 2 < nkA) dmaA(kt + 2);                        // into the stage read during K-tile kt-1 (every wave is past its barrier)
-    FSTAMP(0);                                             // copies issued
-    const char* st = ring + (kt % 3) * FF_A_STAGE;
+    FSTAMP(0);
+    const int st = FF_RING + (kt % 3) * FF_A_STAGE;
     mma_tile(st, st + 8192);
-    if (kt + 2 < nkA) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");      // all but K-tile kt+2's copies
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    FSTAMP(3);                                             // next K-tile's copies landed
+    FSTAMP(3);
     __builtin_amdgcn_s_barrier();
-    FSTAMP(4);                                             // barrier
+    FSTAMP(4);                                             // barrier: K-tile kt+1 landed, everyone done with K-tile kt
   }
-  // every copy and load so far has landed (the loop's last waits were vmcnt(0)); said with the BUILTIN so that the compiler's wait
-  // insertion knows it too and does not put its own vmcnt(0) in front of the first use of `upre` -- behind the copies issued next
-  __builtin_amdgcn_s_waitcnt(0x0F70);
   // ---- phase A epilogue: bias + activation (forward) / times act'(u) (backward); intermediate -> LDS images + global ---------
-  // Phase B's first three stages start now: the ring is free (every wave is past the last barrier of phase A).
-  const int nB = nch * 4;
-  {
-    dmaB(0);
-    dmaB(1);
-    dmaB(2);                                                                  // nB >= 4 always (D >= 256)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = wm * 32 + i * 16 + r16;
+  for (int i = 0; i < 2; ++i) {
+    const int row = wm * 32 + i * 16 + r16;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {                      // tiles 2h, 2h+1 = 8 consecutive columns
-        float v[8];
+    for (int h = 0; h < 2; ++h) {                        // tiles 2h, 2h+1 = 8 consecutive columns
+      float v[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * h][e]; v[4 + e] = acc[i][2 * h + 1][e]; }
-        const size_t go = (size_t)(bm0 + row) * FF_F + wn * 64 + h * 32 + g * 8;
-        if constexpr (!BWD) {
-          v[0] += b1[h][0].x; v[1] += b1[h][0].y; v[2] += b1[h][0].z; v[3] += b1[h][0].w;
-          v[4] += b1[h][1].x; v[5] += b1[h][1].y; v[6] += b1[h][1].z; v[7] += b1[h][1].w;
-          uint4 pre;
-          pre.x = pack_bf16x2(v[0], v[1]); pre.y = pack_bf16x2(v[2], v[3]); pre.z = pack_bf16x2(v[4], v[5]); pre.w = pack_bf16x2(v[6], v[7]);
-          *reinterpret_cast<uint4*>(a.Uout + go) = pre;
+      for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * h][e]; v[4 + e] = acc[i][2 * h + 1][e]; }
+      const size_t go = (size_t)(bm0 + row) * FF_F + wn * 64 + h * 32 + g * 8;
+      if constexpr (!BWD) {
+        v[0] += b1[h][0].x; v[1] += b1[h][0].y; v[2] += b1[h][0].z; v[3] += b1[h][0].w;
+        v[4] += b1[h][1].x; v[5] += b1[h][1].y; v[6] += b1[h][1].z; v[7] += b1[h][1].w;
+        uint4 pre;
+        pre.x = pack_bf16x2(v[0], v[1]); pre.y = pack_bf16x2(v[2], v[3]); pre.z = pack_bf16x2(v[4], v[5]); pre.w = pack_bf16x2(v[6], v[7]);
+        *reinterpret_cast<uint4*>(a.Uout + go) = pre;     // rows past M: padding rows of the caller's buffer
 #pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] = a.relu ? fmaxf(v[r], 0.0f) : gelu_erf_f(v[r]);
-        } else {
-          const unsigned uw[4] = {upre[i][h].x, upre[i][h].y, upre[i][h].z, upre[i][h].w};
-          // the two-launch path rounds the data gradient to bf16 first and then multiplies (mts_gelu_bwd works on the stored tensor)
+        for (int r = 0; r < 8; ++r) v[r] = a.relu ? fmaxf(v[r], 0.0f) : gelu_erf_f(v[r]);
+      } else {
+        const unsigned uw[4] = {upre[i][h].x, upre[i][h].y, upre[i][h].z, upre[i][h].w};
+        // the two-launch path rounds the data gradient to bf16 first and then multiplies (mts_gelu_bwd works on the stored tensor)
 #pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            const float uu = (r & 1) ? bf16_hi(uw[r >> 1]) : bf16_lo(uw[r >> 1]);
-            const float dr = to_f32(from_f32<bf16_t>(v[r]));
-            v[r] = a.relu ? (uu > 0.0f ? dr : 0.0f) : dr * gelu_erf_grad_f(uu);
-          }
-        }
-        u32x4 t;
-        t[0] = pack_bf16x2(v[0], v[1]); t[1] = pack_bf16x2(v[2], v[3]); t[2] = pack_bf16x2(v[4], v[5]); t[3] = pack_bf16x2(v[6], v[7]);
-        *reinterpret_cast<u32x4*>(a.T + go) = t;
-        // K-major image wn (k = the wave's 64 columns): the 8 columns are 16-byte chunk h*4 + g of the row
-        // (inline asm: behind a plain LDS store the compiler waits for the three LDS-DMA stages just requested -- it cannot tell
-        // the image from the ring)
-        {
-          const unsigned la = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(fimg + wn * 8192 + kmajor_off(row, h * 4 + g));
-          asm volatile("ds_write_b128 %0, %1" ::"v"(la), "v"(t) : "memory");
+        for (int r = 0; r < 8; ++r) {
+          const float uu = (r & 1) ? bf16_hi(uw[r >> 1]) : bf16_lo(uw[r >> 1]);
+          const float dr = to_f32(from_f32<bf16_t>(v[r]));
+          v[r] = a.relu ? (uu > 0.0f ? dr : 0.0f) : dr * gelu_erf_grad_f(uu);
         }
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      uint4 t;
+      t.x = pack_bf16x2(v[0], v[1]); t.y = pack_bf16x2(v[2], v[3]); t.z = pack_bf16x2(v[4], v[5]); t.w = pack_bf16x2(v[6], v[7]);
+      *reinterpret_cast<uint4*>(a.T + go) = t;
+      // K-major image wn (k = the wave's 64 columns): the 8 columns are 16-byte chunk h*4 + g of the row
+      *reinterpret_cast<uint4*>(fimg + wn * 8192 + kmajor_off(row, h * 4 + g)) = t;
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  // Everything so far has to be out of the counter before phase B's counted waits start (the stores above would otherwise sit
-  // in front of its copies): one full drain per workgroup.
   FSTAMP(5);                                               // phase A epilogue issued
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                            // the intermediate is complete in LDS; stages 0..2 of phase B have landed
-  FSTAMP(6);                                               // drain + barrier
+  __builtin_amdgcn_s_barrier();                            // the intermediate is complete in LDS; stage 0 of phase B has landed
+  FSTAMP(6);
 #ifdef FFN_STAMPS
   tb = 8;
 #endif
 
   // =============================== phase B: Y[64, D] = T[64, 256] . Wb (+ bias) + residual ====================================
-  // Per output chunk c (256 columns): 4 K-steps kk; copies run three steps ahead (4-stage ring).  Vector-memory operations of a
-  // step, in issue order:   kk == 0: [epilogue loads of chunk c: 4 bias + 4 residual = 8 (backward: 4)] [copies of step g+3: 4]
-  //                         kk == 3: ... [4 output stores of chunk c]
-  // At the end of step g the copies of step g+1 (issued at step g-2, before anything listed for steps g-2 .. g) must have landed:
-  // allowed outstanding = 4 (g+2) + 4 (g+3) + loads / stores issued in steps g-2 .. g behind them.
-  constexpr int EL = BWD ? 4 : 8;                          // epilogue loads per chunk and wave (16 bytes per lane each)
-  constexpr int ST = 4;                                    // output stores per chunk and wave
-  f32x4 b2[2][2];
-  u32x4 res[2][2];
+  // Per output chunk c (256 columns): 4 K-steps kk.  The chunk's epilogue operands are requested at its first step and used at
+  // its last; its stores drain during the next chunk.
+  float4 b2[2][2];
+  uint4 res[2][2];
 #pragma clang loop unroll(disable)
   for (int c = 0; c < nch; ++c) {
     const int colw = c * 256 + wn * 64 + g * 8;            // + h * 32: this lane's 8 columns of half h
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int gi = c * 4 + kk;
-      if (kk == 0) {
-        // inline-asm loads: the compiler does not count LDS-DMA operations, so behind a plain load it would wait for EVERY copy in
-        // flight (vmcnt(0)) at the first use three steps later; the waits that cover these loads are the counted ones below
+      if (kk == 3) {                                       // (the bias one step before its use only: registers)
         if constexpr (!BWD) {
 #pragma unroll
           for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-              const float* bp = a.bb + colw + h * 32 + e * 4;
-              asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b2[h][e]) : "v"(bp) : "memory");
-            }
+            for (int e = 0; e < 2; ++e) b2[h][e] = *reinterpret_cast<const float4*>(a.bb + colw + h * 32 + e * 4);
         }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const bf16_t* rp = a.X + (size_t)min(bm0 + wm * 32 + i * 16 + r16, M - 1) * D + colw + h * 32;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(res[i][h]) : "v"(rp) : "memory");
-          }
       }
-      if (gi + 3 < nB) dmaB(gi + 3);
-      FSTAMP(8);
-      mma_tile(fimg + kk * 8192, ring + (gi & 3) * FF_B_STAGE);
-      if (kk == 3) {
-        // the epilogue loads landed behind step kk = 2's counted wait: tie the registers to this point
-        if constexpr (!BWD) {
-#pragma unroll
-          for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) asm volatile("" : "+v"(b2[h][e]));
-        }
+      if (kk == 1) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int h = 0; h < 2; ++h) asm volatile("" : "+v"(res[i][h]));
+          for (int h = 0; h < 2; ++h)
+            res[i][h] = *reinterpret_cast<const uint4*>(a.X + (size_t)min(bm0 + wm * 32 + i * 16 + r16, M - 1) * D + colw + h * 32);
+      }
+      FSTAMP(8);
+      mma_tile(kk * 8192, FF_RING + kk * FF_B_STAGE);      // stage gi & 3 = kk
+      if (kk == 3) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int row = bm0 + wm * 32 + i * 16 + r16;
@@ -343,40 +349,26 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(const FfnArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * h][e]; v[4 + e] = acc[i][2 * h + 1][e]; }
             if constexpr (!BWD) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) { v[e] += b2[h][0][e]; v[4 + e] += b2[h][1][e]; }
+              v[0] += b2[h][0].x; v[1] += b2[h][0].y; v[2] += b2[h][0].z; v[3] += b2[h][0].w;
+              v[4] += b2[h][1].x; v[5] += b2[h][1].y; v[6] += b2[h][1].z; v[7] += b2[h][1].w;
             }
+            const unsigned rw[4] = {res[i][h].x, res[i][h].y, res[i][h].z, res[i][h].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[2 * e] += bf16_lo(res[i][h][e]); v[2 * e + 1] += bf16_hi(res[i][h][e]); }
-            u32x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-            // unconditional: rows past M land in the padding rows the caller provides (ceil(M / 64) * 64 rows), so that every wave
-            // issues exactly ST stores per chunk -- the counted waits below depend on it
-            *reinterpret_cast<u32x4*>(a.Y + (size_t)row * D + colw + h * 32) = o;
+            for (int e = 0; e < 4; ++e) { v[2 * e] += bf16_lo(rw[e]); v[2 * e + 1] += bf16_hi(rw[e]); }
+            uint4 o;
+            o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+            *reinterpret_cast<uint4*>(a.Y + (size_t)row * D + colw + h * 32) = o;      // rows past M: the caller's padding rows
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
       }
-      // ---- counted wait (see the table above); near the end of the stream fewer copies are in flight: wait for everything ----
-      if (gi + 3 < nB) {
-        if (kk <= 1) { if (c == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + EL) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + EL + ST) : "memory"); }
-        else if (kk == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // also covers this chunk's epilogue loads
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + ST) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      FSTAMP(11);                                          // (kk == 3: epilogue issue +) counted wait
+      FSTAMP(11);
       __builtin_amdgcn_s_barrier();
       FSTAMP(12);
     }
   }
-#ifdef FFN_STAMPS
-  if (a.stamps && lane == 0)
-    for (int i = 0; i < 16; ++i) a.stamps[((size_t)blockIdx.x * 8 + wave) * 16 + i] = tacc[i];
-#endif
+  FF_STAMPS_OUT();
 }
 
 #ifdef FFN_STAMPS
@@ -393,12 +385,12 @@ static int ffn_launch(bool bwd, hipStream_t st, const FfnArgs& a0) {
     auto k = ffn_fused_kernel<true>;
     static bool attr = false;
     if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS) != hipSuccess) { mts_set_error("ffn_fused: cannot reserve %d bytes of LDS", FF_LDS); return MTS_ERR_LAUNCH; } attr = true; }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(512), FF_LDS, st, a);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(FF_THREADS), FF_LDS, st, a);
   } else {
     auto k = ffn_fused_kernel<false>;
     static bool attr = false;
     if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS) != hipSuccess) { mts_set_error("ffn_fused: cannot reserve %d bytes of LDS", FF_LDS); return MTS_ERR_LAUNCH; } attr = true; }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(512), FF_LDS, st, a);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(FF_THREADS), FF_LDS, st, a);
   }
   MTS_LAUNCH_CHECK("mts_ffn_fused");
   return MTS_OK;

@@ -22,7 +22,7 @@ lib.mts_ffn_fwd.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, 
 lib.mts_ffn_bwd_data.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp]
 lib.mts_ffn_set_stamps.argtypes = [vp]
 nwg = Mp // 64
-stamps = torch.zeros(nwg, 8, 16, dtype=torch.int64, device=dev)
+stamps = torch.zeros(nwg, 12, 16, dtype=torch.int64, device=dev)
 NAMES = {0: 'A copies issued', 1: 'A operand reads', 2: 'A MFMA issue', 3: 'A wait copies', 4: 'A barrier', 5: 'A epilogue issue', 6: 'A drain+barrier',
          8: 'B copies (+epi loads) issued', 9: 'B operand reads', 10: 'B MFMA issue', 11: 'B (epilogue+) wait', 12: 'B barrier'}
 for which in ('fwd', 'bwd'):
@@ -35,9 +35,9 @@ for which in ('fwd', 'bwd'):
         assert rc == 0
     torch.cuda.synchronize()
     t = stamps.double().cpu()
-    tot = t.sum(-1).mean().item()
+    tot = t[:, :8].sum(-1).mean().item()
     print('--- %s  M=%d: mean cycles per wave %.0f (s_memtime ticks; 28 + 28 steps)' % (which, M, tot))
     for i, n in NAMES.items():
         steps = 28 if i not in (5, 6) else 1
-        print('   %-30s total %8.0f  per step %7.0f   (wave 0: %7.0f  wave 7: %7.0f)' % (n, t[:, :, i].mean().item(), t[:, :, i].mean().item() / steps,
-                                                                                        t[:, 0, i].mean().item() / steps, t[:, 7, i].mean().item() / steps))
+        print('   %-30s total %8.0f  per step %7.0f   (wave 0: %7.0f  wave 7: %7.0f  copy wave 8: %7.0f  11: %7.0f)' % (n, t[:, :8, i].mean().item(), t[:, :8, i].mean().item() / steps,
+                                                                                        t[:, 0, i].mean().item() / steps, t[:, 7, i].mean().item() / steps, t[:, 8, i].mean().item() / steps, t[:, 11, i].mean().item() / steps))
