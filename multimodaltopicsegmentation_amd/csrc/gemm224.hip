@@ -19,7 +19,7 @@
 #include <math.h>
 #include "gemm_common.h"
 
-#ifdef MTS_GEMM_STAMPS
+#if defined(MTS_GEMM_STAMPS) && !defined(G224_PHASES)
 #define STAMP(slot) do { if (a.stamps && tid == 0) { a.stamps[((size_t)blockIdx.x * 8 + round) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
                                                       if ((slot) == 0) a.stamps[((size_t)blockIdx.x * 8 + round) * 8 + 6] = __builtin_amdgcn_s_memrealtime(); \
                                                       if ((slot) == 3) a.stamps[((size_t)blockIdx.x * 8 + round) * 8 + 5] = __builtin_amdgcn_s_memrealtime(); \
@@ -36,6 +36,11 @@
 #define BN224 224
 #define HN224 112
 
+#ifdef G224_PHASES                      // per-wave cycle sums per phase of the K loop (tools/micro/gemm224_phases.py); needs MTS_GEMM_STAMPS
+#define PST(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[i] += t_ - pprev; pprev = t_; } while (0)
+#else
+#define PST(i) do { } while (0)
+#endif
 #ifdef MTS_GEMM_STAMPS
 static unsigned long long* g_gemm_stamps = nullptr;
 extern "C" void mts_gemm_set_stamps(void* p) { g_gemm_stamps = (unsigned long long*)p; }
@@ -217,11 +222,21 @@ struct Epi224 {
 // PERSIST = false: one tile per workgroup.  The workgroup ends right behind its last store instruction, so the stores drain
 // while the CU's next workgroup starts its K loop, and no state of a next tile lives across the epilogue (the persistent form
 // keeps ~60 registers of it and the fast epilogue spills around every store there).
-// ONEBAR = true: ONE workgroup barrier per K-tile.  A is copied two K-tiles ahead into three images (activations: L2 misses are
-// served by the Infinity Cache / HBM), B only ONE K-tile ahead into two images (weights: L2 hits), issued right behind the
-// barrier that freed its image -- so no image is overwritten inside the K-tile that reads it and the mid-tile barrier (with the
-// burst of LDS reads behind it) is gone.  ONEBAR = false is the round-1 schedule (both operands two ahead, B recycled mid-tile).
-template <int LAYOUT, typename TC, bool PERSIST, bool ONEBAR>
+// One workgroup barrier per K-tile in both schedules.
+// MIDBAR = false (gemm_variant 5): the barrier sits at the END of the K-tile.  A is copied two K-tiles ahead into three images, B one
+// K-tile ahead into two, issued right behind the barrier that freed its image.  Every wave starts a K-tile by requesting its 18
+// first fragments: the LDS needs ~400 cycles to serve the 8 waves and the matrix cores trickle until it has (in-kernel stamps,
+// tools/micro/gemm224_phases.py: the first 16 MFMAs of a K-tile take 720-1600 cycles, the other 40 run at the pipe's rate).
+// MIDBAR = true (default): the products of a K-tile are ordered  b1 x aA, b1 x aB | b0 x aA, b0 x aB  (b0 / b1: columns 0-63 /
+// 64-111 of the wave's B half, aA / aB: rows 0-31 / 32-63 of its A rows).  All LDS reads of the tile are done after the second
+// product, so the barrier sits THERE; behind it the wave already fetches the next K-tile's b1 (its registers are free) and, one
+// product later, its aA -- while the 32 MFMAs of the last two products run.  The next K-tile starts with b1 x aA on registers
+// that landed long ago: no MFMA waits for the LDS at a K-tile boundary, and the burst of reads (aB, b0) has 24 MFMAs to hide
+// behind.  A lives in two images (K-tile parity), B in three: B(kt+2) is copied under the first two products of K-tile kt, A(kt+2)
+// under the last two (behind the barrier that freed its image) -- a full K-tile for either to land, and the CU's copy queue
+// (~24 cycles per 1-KiB copy, 64 copies per K-tile) is loaded evenly.  The bf16 store staging aliases the third B image.
+// Accumulation order per output element is unchanged (bitwise equal).  Measured (in-process A/B, tools/gemm_ab_libs.py @0 vs @5).
+template <int LAYOUT, typename TC, bool PERSIST, bool MIDBAR>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a) {
   constexpr bool A_KMAJOR = (LAYOUT == MTS_NT || LAYOUT == MTS_NN);
   constexpr bool B_KMAJOR = (LAYOUT == MTS_NT || LAYOUT == MTS_TT);
@@ -232,7 +247,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a)
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave_u >> 1, wn = wave_u & 1;
   const int r16 = lane & 15, g = lane >> 4;
-  char* stage = smem + 2 * A_BYTES + wave_u * 4096;
+  constexpr int B_OFF = MIDBAR ? 2 * A_BYTES : B_BASE;           // MIDBAR: two A images, THREE B images (the store staging aliases the third)
+  char* stage = smem + (MIDBAR ? 2 * A_BYTES + 4 * HT_BYTES : 2 * A_BYTES) + wave_u * 4096;
 
   const int ntn = a.N / BN224;
   const int ntm = (a.M + 255) / 256;
@@ -259,20 +275,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a)
     bn0 = (within / rows) * BN224;
   };
   int bm0, bn0;
-  // A(kt) lives in A image kt % 3 (`ab`), B(kt) in B image kt & 1; both are copied TWO K-tiles ahead
+  // MIDBAR = false: A(kt) lives in A image kt % 3 (`ab`), B(kt) in B image kt & 1;  MIDBAR = true: both in images kt & 1
   auto dmaA = [&](int h, int kt, int ab) {
     dma_half<A_KMAJOR>(A, a.lda, bm0 + h * 128, a.M, kbeg + kt * BK, smem + ab * A_BYTES + h * HT_BYTES, wave_u, lane);
   };
-  auto dmaB = [&](int h, int kt) {
-    dma_half<B_KMAJOR>(B, a.ldb, bn0 + h * HN224, a.N, kbeg + kt * BK, smem + B_BASE + ((kt & 1) * 2 + h) * HT_BYTES, wave_u, lane);
+  auto dmaB = [&](int h, int kt, int img) {
+    dma_half<B_KMAJOR>(B, a.ldb, bn0 + h * HN224, a.N, kbeg + kt * BK, smem + B_OFF + (img * 2 + h) * HT_BYTES, wave_u, lane);
   };
   // copy instructions per wave and K-tile: 4 for A, 4 for B.  Issue order matters for the counted waits (in-order counter).
-  constexpr int LOOP_LEAD = ONEBAR ? 4 : 8;      // copies of one loop iteration that may still be in flight at its end
   auto prologue = [&]() {
     if (nk > 0) {
-      dmaB(0, 0); dmaB(1, 0); dmaA(0, 0, 0); dmaA(1, 0, 0);
+      dmaB(0, 0, 0); dmaB(1, 0, 0); dmaA(0, 0, 0); dmaA(1, 0, 0);
       if (nk > 1) {
-        if constexpr (!ONEBAR) { dmaB(0, 1); dmaB(1, 1); }
+        if constexpr (MIDBAR) { dmaB(0, 1, 1); dmaB(1, 1, 1); }
         dmaA(0, 1, 1); dmaA(1, 1, 1);
       }
     }
@@ -287,7 +302,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a)
   if (t >= nt) return;
   tile_origin(t, bm0, bn0);
   auto wait_first_tile = [&]() {                 // K-tile 0 has landed: everything but the copies of K-tile 1
-    if (nk > 1) { if constexpr (ONEBAR) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    if (nk > 1) { if constexpr (MIDBAR) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   prologue();
@@ -298,6 +313,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a)
   // moved up so that the next K-tile's first fragments are fetched in phase 4 -- measured 5-15 % SLOWER than this simple
   // form on MI355X, so LDS latency is not what holds the K-tile at ~2x its pure MFMA time; see DESIGN.md.)
   int round = 0;
+#ifdef G224_PHASES
+  unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long pprev = __builtin_amdgcn_s_memtime();
+#endif
   for (;;) {
     STAMP(0);
 #pragma unroll
@@ -305,11 +324,150 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a)
 #pragma unroll
       for (int j = 0; j < 7; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    if constexpr (MIDBAR) {
+      constexpr int cb = lfrag_ops<B_KMAJOR>::value, ca = lfrag_ops<A_KMAJOR>::value;
+      auto a_img = [&](int kt) { return (const char*)(smem + (kt & 1) * A_BYTES + (wm >> 1) * HT_BYTES); };
+      auto b_img = [&](int img) { return (const char*)(smem + B_OFF + (img * 2 + wn) * HT_BYTES); };
+      // Fragment addresses = lane part (loop-invariant registers) + image base (one add per K-tile) + instruction immediate.
+      //   K-major:  kmajor_off(16 t + r16, ks*4 + g) = t * 2048 + lk[ks]              -- 2 lane registers per kernel
+      //   strided:  strided_off(ks*32 + 8g + q, 16 c + 4p) = ks * 8192 + (sx ^ (c << 5)) -- one lane register per column block c
+      // One address register per fragment (what the generic lfrag_read costs once the compiler has hoisted it out of the loop,
+      // twice for the two image parities) does not fit next to 112 accumulators and 88 fragment registers: it spilled fragment
+      // registers whose LDS data had not arrived yet.
+      const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+      unsigned lk[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) lk[ks] = r16 * 128 + (((ks * 4 + g) ^ ((r16 >> 1) & 7)) << 4);
+      const int q_ = r16 >> 2, p_ = r16 & 3;
+      const unsigned sx = (8 * g + q_) * 256 + 8 * p_ + ((((8 * g + q_) & 3) | ((g & 1) << 2)) << 5);   // strided_off(8g + q, 4p), column block 0
+      const unsigned sxa = sx ^ ((arow >> 4) << 5);          // the wave's 64 A rows start at column block arow / 16 of the image half
+      // (The lane parts go through an empty asm at every use: otherwise the compiler hoists one address per fragment out of the
+      // loops again -- and spills them, reloading through the vector-memory counter behind the copies in flight.)
+      // t2 = first 16-row (column) block of the group inside the wave's 64 A rows: 0 (aA) or 2 (aB)
+      auto rd_a = [&](LFrag<A_KMAJOR> (&f)[2][2], const char* At, auto T2) {
+        constexpr int t2 = decltype(T2)::value;
+        const unsigned ib = lds0 + (unsigned)(At - smem);
+        if constexpr (A_KMAJOR) {
+          unsigned l0 = lk[0], l1 = lk[1];
+          asm volatile("" : "+v"(l0), "+v"(l1));
+          const unsigned b0_ = ib + arow * 128 + l0, b1_ = ib + arow * 128 + l1;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[i][0].k) : "v"(b0_), "n"((t2 + i) * 2048));
+#pragma unroll
+          for (int i = 0; i < 2; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[i][1].k) : "v"(b1_), "n"((t2 + i) * 2048));
+        } else {
+          unsigned sl = sxa;
+          asm volatile("" : "+v"(sl));
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const unsigned ad = ib + (sl ^ ((t2 + i) << 5));
+              if (ks == 0) {
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f[i][0].s.lo) : "v"(ad));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(f[i][0].s.hi) : "v"(ad));
+              } else {
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(f[i][1].s.lo) : "v"(ad));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:9216" : "=v"(f[i][1].s.hi) : "v"(ad));
+              }
+            }
+        }
+      };
+      // c0 = first 16-column block of the group inside the wave's B half: 0 (b0: 4 blocks) or 4 (b1: 3 blocks)
+      auto rd_b = [&](auto& fb, const char* Bt, auto C0, auto NJ) {
+        constexpr int c0 = decltype(C0)::value, nj = decltype(NJ)::value;
+        const unsigned ib = lds0 + (unsigned)(Bt - smem);
+        if constexpr (B_KMAJOR) {
+          unsigned l0 = lk[0], l1 = lk[1];
+          asm volatile("" : "+v"(l0), "+v"(l1));
+          const unsigned b0_ = ib + l0, b1_ = ib + l1;
+#pragma unroll
+          for (int j = 0; j < nj; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[j][0].k) : "v"(b0_), "n"((c0 + j) * 2048));
+#pragma unroll
+          for (int j = 0; j < nj; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[j][1].k) : "v"(b1_), "n"((c0 + j) * 2048));
+        } else {
+          unsigned sl = sx;
+          asm volatile("" : "+v"(sl));
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < nj; ++j) {
+              const unsigned ad = ib + (sl ^ ((c0 + j) << 5));
+              if (ks == 0) {
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fb[j][0].s.lo) : "v"(ad));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(fb[j][0].s.hi) : "v"(ad));
+              } else {
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(fb[j][1].s.lo) : "v"(ad));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:9216" : "=v"(fb[j][1].s.hi) : "v"(ad));
+              }
+            }
+        }
+      };
+      using I0 = std::integral_constant<int, 0>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+      using I4 = std::integral_constant<int, 4>;
+      auto rd_b0 = [&](const char* Bt) { rd_b(fb0, Bt, I0{}, I4{}); };
+      auto rd_b1 = [&](const char* Bt) { rd_b(fb1, Bt, I4{}, I3{}); };
+      // K-tile 0 has landed (barrier above / at the end of the previous round): its first product's operands
+      if (nk > 0) { rd_b1(b_img(0)); rd_a(faA, a_img(0), I0{}); }
+      int bb = 0;                                  // kt % 3: B image of this K-tile
+#pragma clang loop unroll(disable)
+      for (int kt = 0; kt < nk; ++kt) {
+        // outstanding LDS operations, oldest first: [b1 6cb, aA 4ca] (requested during the previous K-tile), aB 4ca, b0 8cb
+        rd_a(faB, a_img(kt), I2{});
+        rd_b0(b_img(bb));
+        const int bb1 = bb == 2 ? 0 : bb + 1, bb2 = bb == 0 ? 2 : bb - 1;      // (kt + 1) % 3, (kt + 2) % 3
+        const bool nxt = kt + 1 < nk, cpy = kt + 2 < nk;
+        // one product: acc[i0 + i][j0 + j] += B fragment j x A fragment i, ks = 0 then 1 (the order every schedule uses).  The MFMA
+        // operands are formed right before their use: for strided operands that is a register copy, kept short-lived.
+        auto product = [&](auto& fbx, auto& fax, auto J0, auto NJ, auto I0_, auto&& between) {
+          constexpr int j0 = decltype(J0)::value, nj = decltype(NJ)::value, i0 = decltype(I0_)::value;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 vb[nj];
+#pragma unroll
+            for (int j = 0; j < nj; ++j) vb[j] = lfrag_get<B_KMAJOR>(fbx[j][ks]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const bf16x8 va = lfrag_get<A_KMAJOR>(fax[i][ks]);
+#pragma unroll
+              for (int j = 0; j < nj; ++j) acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb[j], va, acc[i0 + i][j0 + j], 0, 0, 0);
+            }
+            between(ks);
+          }
+        };
+        auto nothing = [](int) {};
+        __builtin_amdgcn_s_setprio(1);
+        lgkm_wait<4 * ca + 8 * cb>();                // b1, aA
+        // B(kt+2) goes out under the first two products (its image was last read before the barrier of K-tile kt-1), A(kt+2) under
+        // the last two: 4 copies per wave and half -- the CU's copy queue takes ~24 cycles per copy, 64 copies do not fit under
+        // one half's MFMAs.  A wave stalls while the queue is full; its SIMD partner computes.
+        product(fb1, faA, I4{}, I3{}, I0{}, [&](int ks) { if (cpy && ks == 0) dmaB(0, kt + 2, bb2); });
+        lgkm_wait<8 * cb>();                         // aB
+        product(fb1, faB, I4{}, I3{}, I2{}, [&](int ks) { if (cpy && ks == 0) dmaB(1, kt + 2, bb2); });
+        __builtin_amdgcn_s_setprio(0);
+        // every LDS read of this K-tile has landed; so have this wave's copies of K-tile kt+1 (all but the 4 of B(kt+2) just issued)
+        lgkm_wait<0>();
+        PST(0);                                      // first two products (24 MFMAs) issued, all reads landed
+        if (cpy) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PST(1);                                      // copies landed
+        __builtin_amdgcn_s_barrier();                // images kt & 1 are free, K-tile kt+1 is complete in the other pair
+        PST(2);                                      // barrier
+        if (nxt) rd_b1(b_img(bb1));
+        __builtin_amdgcn_s_setprio(1);
+        product(fb0, faA, I0{}, I4{}, I0{}, [&](int ks) { if (cpy && ks == 0) dmaA(0, kt + 2, kt & 1); });
+        if (nxt) rd_a(faA, a_img(kt + 1), I0{});     // (the MFMAs that read the old aA have been issued)
+        product(fb0, faB, I0{}, I4{}, I2{}, [&](int ks) { if (cpy && ks == 0) dmaA(1, kt + 2, kt & 1); });
+        bb = bb1;
+        PST(3);                                      // last two products (32 MFMAs, 8 copies, 10 reads) issued
+        __builtin_amdgcn_s_setprio(0);
+      }
+    } else {
     int ab = 0;                                   // kt % 3
 #pragma clang loop unroll(disable)
     for (int kt = 0; kt < nk; ++kt) {
       const char* At = smem + ab * A_BYTES + (wm >> 1) * HT_BYTES;
-      const char* Bt = smem + B_BASE + ((kt & 1) * 2 + wn) * HT_BYTES;
+      const char* Bt = smem + B_OFF + ((kt & 1) * 2 + wn) * HT_BYTES;
       const int ab2 = ab == 0 ? 2 : ab - 1;       // (kt + 2) % 3: the A image read one K-step ago
 
       // Fragment reads are asm with counted waits (gemm_common.h "LDS fragment reads the caller waits for").  Per K-tile:
@@ -319,8 +477,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a)
       constexpr int T1 = 14 * cb + 4 * ca;           // LDS operations of the first block of reads
 
       // ---- phase 1 ---------------------------------------------------------------------------
-      if constexpr (ONEBAR) { if (kt + 1 < nk) dmaB(0, kt + 1); }
-      else { if (kt + 2 < nk) dmaA(0, kt + 2, ab2); }
+      if (kt + 1 < nk) dmaB(0, kt + 1, (kt + 1) & 1);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -370,8 +527,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a)
       __builtin_amdgcn_s_setprio(0);
 
       // ---- phase 2 ---------------------------------------------------------------------------
-      if constexpr (ONEBAR) { if (kt + 1 < nk) dmaB(1, kt + 1); }
-      else { if (kt + 2 < nk) dmaA(1, kt + 2, ab2); }
+      if (kt + 1 < nk) dmaB(1, kt + 1, (kt + 1) & 1);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -402,11 +558,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a)
           for (int j = 0; j < 3; ++j) acc[i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb1[j][1], va[i][1], acc[i][4 + j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         lgkm_wait<0>();
-        if constexpr (!ONEBAR) __builtin_amdgcn_s_barrier();   // every wave is done reading this buffer's B images
 
         // ---- phase 3 ---------------------------------------------------------------------------
-        if constexpr (ONEBAR) { if (kt + 2 < nk) dmaA(0, kt + 2, ab2); }
-        else { if (kt + 2 < nk) dmaB(0, kt + 2); }
+        if (kt + 2 < nk) dmaA(0, kt + 2, ab2);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -421,8 +575,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a)
         __builtin_amdgcn_s_setprio(0);
 
         // ---- phase 4 ---------------------------------------------------------------------------
-        if constexpr (ONEBAR) { if (kt + 2 < nk) dmaA(1, kt + 2, ab2); }
-        else { if (kt + 2 < nk) dmaB(1, kt + 2); }
+        if (kt + 2 < nk) dmaA(1, kt + 2, ab2);
         bf16x8 vb0[4][2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -437,16 +590,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a)
             for (int j = 0; j < 4; ++j) acc[2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb0[j][ks], va[i][ks], acc[2 + i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
       }
-      // everything the NEXT K-tile reads has landed: all copies but the youngest LOOP_LEAD of this iteration (A(kt+2), and in the
-      // two-barrier schedule B(kt+2)); near the end of K fewer were issued, so wait for all
-      if (kt + 2 < nk) { if constexpr (ONEBAR) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+      // everything the NEXT K-tile reads has landed: all copies but the youngest 4 of this iteration (A(kt+2)); near the end of
+      // K fewer were issued, so wait for all
+      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       ab = ab == 2 ? 0 : ab + 1;
     }
 
+    }
     STAMP(1);
+#ifdef G224_PHASES
+    if (a.stamps && lane == 0 && round == 0)
+      for (int i = 0; i < 8; ++i) a.stamps[((size_t)(blockIdx.x + gridDim.x * blockIdx.z) * 8 + wave_u) * 8 + i] = pacc[i];
+#endif
     const int m0 = bm0 + wm * 64, n0 = bn0 + wn * HN224;
     bool fast = false;
     if constexpr (sizeof(TC) == 2 && !PERSIST) fast = (a.variant != 1) && epi224_fast_ok(a, bm0);
@@ -492,9 +650,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a)
   }
 }
 
-template <int LAYOUT, typename TC, bool PERSIST, bool ONEBAR>
+template <int LAYOUT, typename TC, bool PERSIST, bool MIDBAR>
 static int launch_one_p(const GemmArgs& a, int splits, hipStream_t st) {
-  auto k = gemm_bf16_224_kernel<LAYOUT, TC, PERSIST, ONEBAR>;
+  auto k = gemm_bf16_224_kernel<LAYOUT, TC, PERSIST, MIDBAR>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
@@ -514,11 +672,15 @@ static int launch_one_p(const GemmArgs& a, int splits, hipStream_t st) {
 }
 
 // bf16 C: one tile per workgroup (the stores of a tile drain while the CU's next workgroup runs its K loop); fp32 C (weight
-// gradients, split-K slabs): persistent.  gemm_variant 5 selects the two-barrier K loop (A/B).
+// gradients, split-K slabs): persistent.  gemm_variant 5 / 6 force the end-of-tile / mid-tile barrier schedule (A/B).
 template <int LAYOUT, typename TC>
 static int launch_one(const GemmArgs& a, int splits, hipStream_t st) {
   constexpr bool persist = sizeof(TC) != 2;
-  if (a.variant == 5) return launch_one_p<LAYOUT, TC, persist, false>(a, splits, st);
+  // Schedule per layout, from the in-process A/B on the BASELINE shapes (tools/gemm_ab_libs.py lib@6 lib@5): the mid-tile barrier
+  // wins 4-7 % with at least one K-major operand (NT forward, NN data gradient), loses 4-8 % with two strided ones (TN weight
+  // gradient: two transposing reads per fragment, the request burst it hides is twice as long).  gemm_variant 5 / 6 force one.
+  const bool mid = a.variant == 6 || (a.variant != 5 && LAYOUT != MTS_TN);
+  if (!mid) return launch_one_p<LAYOUT, TC, persist, false>(a, splits, st);
   return launch_one_p<LAYOUT, TC, persist, true>(a, splits, st);
 }
 
