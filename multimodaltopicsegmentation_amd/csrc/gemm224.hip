@@ -46,10 +46,11 @@ static unsigned long long* g_gemm_stamps = nullptr;
 extern "C" void mts_gemm_set_stamps(void* p) { g_gemm_stamps = (unsigned long long*)p; }
 #endif
 
-template <bool KMAJOR>
+// ONLY >= 0: just that one of the wave's two pieces (the mid-tile-barrier schedule issues its copies one at a time)
+template <bool KMAJOR, int ONLY = -1>
 __device__ __forceinline__ void dma_half(const bf16_t* __restrict__ G, int ld, int row0, int dim, int k0, char* dst, int wave_u, int lane) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = (ONLY < 0 ? 0 : ONLY); i < (ONLY < 0 ? 2 : ONLY + 1); ++i) {
     const int piece = wave_u * 2 + i;   // 16 pieces of 1 KiB, 2 per wave
     const bf16_t* src;
     if constexpr (KMAJOR) {
@@ -282,6 +283,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a)
   auto dmaB = [&](int h, int kt, int img) {
     dma_half<B_KMAJOR>(B, a.ldb, bn0 + h * HN224, a.N, kbeg + kt * BK, smem + B_OFF + (img * 2 + h) * HT_BYTES, wave_u, lane);
   };
+  auto dmaA1 = [&](int h, int kt, int ab, auto I) {
+    dma_half<A_KMAJOR, decltype(I)::value>(A, a.lda, bm0 + h * 128, a.M, kbeg + kt * BK, smem + ab * A_BYTES + h * HT_BYTES, wave_u, lane);
+  };
+  auto dmaB1 = [&](int h, int kt, int img, auto I) {
+    dma_half<B_KMAJOR, decltype(I)::value>(B, a.ldb, bn0 + h * HN224, a.N, kbeg + kt * BK, smem + B_OFF + (img * 2 + h) * HT_BYTES, wave_u, lane);
+  };
   // copy instructions per wave and K-tile: 4 for A, 4 for B.  Issue order matters for the counted waits (in-order counter).
   auto prologue = [&]() {
     if (nk > 0) {
@@ -431,19 +438,20 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a)
               const bf16x8 va = lfrag_get<A_KMAJOR>(fax[i][ks]);
 #pragma unroll
               for (int j = 0; j < nj; ++j) acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb[j], va, acc[i0 + i][j0 + j], 0, 0, 0);
+              if (i == 0) between(ks);                 // in the middle of each ks group: 3-4 MFMAs issued, 3-4 to come
             }
-            between(ks);
           }
         };
-        auto nothing = [](int) {};
+        using I1 = std::integral_constant<int, 1>;
         __builtin_amdgcn_s_setprio(1);
         lgkm_wait<4 * ca + 8 * cb>();                // b1, aA
         // B(kt+2) goes out under the first two products (its image was last read before the barrier of K-tile kt-1), A(kt+2) under
-        // the last two: 4 copies per wave and half -- the CU's copy queue takes ~24 cycles per copy, 64 copies do not fit under
-        // one half's MFMAs.  A wave stalls while the queue is full; its SIMD partner computes.
-        product(fb1, faA, I4{}, I3{}, I0{}, [&](int ks) { if (cpy && ks == 0) dmaB(0, kt + 2, bb2); });
+        // the last two, ONE copy at a time between MFMA groups (8 per wave and K-tile, one per 7 MFMAs): the CU's copy queue takes
+        // ~24 cycles per 1-KiB copy, and a wave whose copy it cannot take yet stalls, MFMAs included -- bursts of 16 queued copies
+        // cost each wave ~90 cycles per copy.
+        product(fb1, faA, I4{}, I3{}, I0{}, [&](int ks) { if (cpy) { if (ks == 0) dmaB1(0, kt + 2, bb2, I0{}); else dmaB1(0, kt + 2, bb2, I1{}); } });
         lgkm_wait<8 * cb>();                         // aB
-        product(fb1, faB, I4{}, I3{}, I2{}, [&](int ks) { if (cpy && ks == 0) dmaB(1, kt + 2, bb2); });
+        product(fb1, faB, I4{}, I3{}, I2{}, [&](int ks) { if (cpy) { if (ks == 0) dmaB1(1, kt + 2, bb2, I0{}); else dmaB1(1, kt + 2, bb2, I1{}); } });
         __builtin_amdgcn_s_setprio(0);
         // every LDS read of this K-tile has landed; so have this wave's copies of K-tile kt+1 (all but the 4 of B(kt+2) just issued)
         lgkm_wait<0>();
@@ -455,9 +463,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a)
         PST(2);                                      // barrier
         if (nxt) rd_b1(b_img(bb1));
         __builtin_amdgcn_s_setprio(1);
-        product(fb0, faA, I0{}, I4{}, I0{}, [&](int ks) { if (cpy && ks == 0) dmaA(0, kt + 2, kt & 1); });
+        product(fb0, faA, I0{}, I4{}, I0{}, [&](int ks) { if (cpy) { if (ks == 0) dmaA1(0, kt + 2, kt & 1, I0{}); else dmaA1(0, kt + 2, kt & 1, I1{}); } });
         if (nxt) rd_a(faA, a_img(kt + 1), I0{});     // (the MFMAs that read the old aA have been issued)
-        product(fb0, faB, I0{}, I4{}, I2{}, [&](int ks) { if (cpy && ks == 0) dmaA(1, kt + 2, kt & 1); });
+        product(fb0, faB, I0{}, I4{}, I2{}, [&](int ks) { if (cpy) { if (ks == 0) dmaA1(1, kt + 2, kt & 1, I0{}); else dmaA1(1, kt + 2, kt & 1, I1{}); } });
         bb = bb1;
         PST(3);                                      // last two products (32 MFMAs, 8 copies, 10 reads) issued
         __builtin_amdgcn_s_setprio(0);
