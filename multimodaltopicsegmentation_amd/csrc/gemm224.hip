@@ -49,6 +49,9 @@ extern "C" void mts_gemm_set_stamps(void* p) { g_gemm_stamps = (unsigned long lo
 // ONLY >= 0: just that one of the wave's two pieces (the mid-tile-barrier schedule issues its copies one at a time)
 template <bool KMAJOR, int ONLY = -1>
 __device__ __forceinline__ void dma_half(const bf16_t* __restrict__ G, int ld, int row0, int dim, int k0, char* dst, int wave_u, int lane) {
+#ifdef G224_DBG_NO_DMA                  // timing experiment only (tools/micro/gemm224_variants.sh): the K loop without its copies
+  return;
+#endif
 #pragma unroll
   for (int i = (ONLY < 0 ? 0 : ONLY); i < (ONLY < 0 ? 2 : ONLY + 1); ++i) {
     const int piece = wave_u * 2 + i;   // 16 pieces of 1 KiB, 2 per wave
@@ -316,9 +319,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a)
   wait_first_tile();
   __builtin_amdgcn_s_barrier();
 
-  // (A register-pipelined variant -- fragments of phase p+1 fetched from LDS under the MFMAs of phase p, second barrier
-  // moved up so that the next K-tile's first fragments are fetched in phase 4 -- measured 5-15 % SLOWER than this simple
-  // form on MI355X, so LDS latency is not what holds the K-tile at ~2x its pure MFMA time; see DESIGN.md.)
   int round = 0;
 #ifdef G224_PHASES
   unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
