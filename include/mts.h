@@ -62,7 +62,7 @@ typedef enum { MTS_NT = 0, MTS_NN = 1, MTS_TN = 2, MTS_TT = 3 } mts_gemm_layout;
 const char* mts_last_error(void);
 /* version / build info: "mts-hip <n> gfx950" */
 const char* mts_version(void);
-/* tuning / A-B switches: "gemm_variant" = 0 | 1 (generic epilogue in the 256x224 kernel) | 5 / 6 (its K loop with the barrier at the end / in the middle of the K-tile for every layout) ; "gemm_f32_mfma" = 1
+/* tuning / A-B switches: "gemm_variant" = 0 | 1 (generic epilogue in the 256x224 kernel) | 5 (its K loop with the barrier at the end of the K-tile for every layout) ; "gemm_f32_mfma" = 1
  * (fp32 GEMM on v_mfma_f32_16x16x4_f32) | 0 (VALU kernel, bitwise the same results) ; "gemm_tile" = 0 (cost model) | 128 | 224 | 256 ; "gemm_glds" = 1 (LDS-DMA staging) | 0 (register
  * staging) ; "gemm_splits" = 0 (cost model) | n ; "gemm_order" = 1 (L2-blocked tile order) | 0 ; "gemm_chain" = 0 | 1 (split-K
  * of the 128x128 kernel accumulates in place) ; "gemm_deep" = 1 (four-buffer copy pipeline of the 128x128 kernel for grids of at

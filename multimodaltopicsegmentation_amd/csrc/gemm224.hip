@@ -426,18 +426,24 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a)
         const bool nxt = kt + 1 < nk, cpy = kt + 2 < nk;
         // one product: acc[i0 + i][j0 + j] += B fragment j x A fragment i, ks = 0 then 1 (the order every schedule uses).  The MFMA
         // operands are formed right before their use: for strided operands that is a register copy, kept short-lived.
-        auto product = [&](auto& fbx, auto& fax, auto J0, auto NJ, auto I0_, auto&& between) {
+        // MFMA operands: formed ONCE per fragment, at its first product (for a strided operand that joins the two halves of the
+        // transposing reads; formed again at the second product the compiler copied registers: 68 moves per K-tile in the TN loop),
+        // and kept for the second.  The raw fragment registers are dead from then on and take the next K-tile's prefetch.
+        bf16x8 ob1[3][2], ob0[4][2], oaA[2][2], oaB[2][2];
+        auto product = [&](auto& fbx, auto& obx, auto& fax, auto& oax, auto J0, auto NJ, auto I0_, auto FORM_B, auto FORM_A, auto&& between) {
           constexpr int j0 = decltype(J0)::value, nj = decltype(NJ)::value, i0 = decltype(I0_)::value;
+          constexpr bool form_b = decltype(FORM_B)::value != 0, form_a = decltype(FORM_A)::value != 0;
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 vb[nj];
+            if constexpr (form_b) {
 #pragma unroll
-            for (int j = 0; j < nj; ++j) vb[j] = lfrag_get<B_KMAJOR>(fbx[j][ks]);
+              for (int j = 0; j < nj; ++j) obx[j][ks] = lfrag_get<B_KMAJOR>(fbx[j][ks]);
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-              const bf16x8 va = lfrag_get<A_KMAJOR>(fax[i][ks]);
+              if constexpr (form_a) oax[i][ks] = lfrag_get<A_KMAJOR>(fax[i][ks]);
 #pragma unroll
-              for (int j = 0; j < nj; ++j) acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb[j], va, acc[i0 + i][j0 + j], 0, 0, 0);
+              for (int j = 0; j < nj; ++j) acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(obx[j][ks], oax[i][ks], acc[i0 + i][j0 + j], 0, 0, 0);
               if (i == 0) between(ks);                 // in the middle of each ks group: 3-4 MFMAs issued, 3-4 to come
             }
           }
@@ -449,9 +455,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a)
         // the last two, ONE copy at a time between MFMA groups (8 per wave and K-tile, one per 7 MFMAs): the CU's copy queue takes
         // ~24 cycles per 1-KiB copy, and a wave whose copy it cannot take yet stalls, MFMAs included -- bursts of 16 queued copies
         // cost each wave ~90 cycles per copy.
-        product(fb1, faA, I4{}, I3{}, I0{}, [&](int ks) { if (cpy) { if (ks == 0) dmaB1(0, kt + 2, bb2, I0{}); else dmaB1(0, kt + 2, bb2, I1{}); } });
+        product(fb1, ob1, faA, oaA, I4{}, I3{}, I0{}, I1{}, I1{}, [&](int ks) { if (cpy) { if (ks == 0) dmaB1(0, kt + 2, bb2, I0{}); else dmaB1(0, kt + 2, bb2, I1{}); } });
         lgkm_wait<8 * cb>();                         // aB
-        product(fb1, faB, I4{}, I3{}, I2{}, [&](int ks) { if (cpy) { if (ks == 0) dmaB1(1, kt + 2, bb2, I0{}); else dmaB1(1, kt + 2, bb2, I1{}); } });
+        product(fb1, ob1, faB, oaB, I4{}, I3{}, I2{}, I0{}, I1{}, [&](int ks) { if (cpy) { if (ks == 0) dmaB1(1, kt + 2, bb2, I0{}); else dmaB1(1, kt + 2, bb2, I1{}); } });
         __builtin_amdgcn_s_setprio(0);
         // every LDS read of this K-tile has landed; so have this wave's copies of K-tile kt+1 (all but the 4 of B(kt+2) just issued)
         lgkm_wait<0>();
@@ -463,9 +469,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a)
         PST(2);                                      // barrier
         if (nxt) rd_b1(b_img(bb1));
         __builtin_amdgcn_s_setprio(1);
-        product(fb0, faA, I0{}, I4{}, I0{}, [&](int ks) { if (cpy) { if (ks == 0) dmaA1(0, kt + 2, kt & 1, I0{}); else dmaA1(0, kt + 2, kt & 1, I1{}); } });
+        product(fb0, ob0, faA, oaA, I0{}, I4{}, I0{}, I1{}, I0{}, [&](int ks) { if (cpy) { if (ks == 0) dmaA1(0, kt + 2, kt & 1, I0{}); else dmaA1(0, kt + 2, kt & 1, I1{}); } });
         if (nxt) rd_a(faA, a_img(kt + 1), I0{});     // (the MFMAs that read the old aA have been issued)
-        product(fb0, faB, I0{}, I4{}, I2{}, [&](int ks) { if (cpy) { if (ks == 0) dmaA1(1, kt + 2, kt & 1, I0{}); else dmaA1(1, kt + 2, kt & 1, I1{}); } });
+        product(fb0, ob0, faB, oaB, I0{}, I4{}, I2{}, I0{}, I0{}, [&](int ks) { if (cpy) { if (ks == 0) dmaA1(1, kt + 2, kt & 1, I0{}); else dmaA1(1, kt + 2, kt & 1, I1{}); } });
         bb = bb1;
         PST(3);                                      // last two products (32 MFMAs, 8 copies, 10 reads) issued
         __builtin_amdgcn_s_setprio(0);
@@ -680,16 +686,21 @@ static int launch_one_p(const GemmArgs& a, int splits, hipStream_t st) {
 }
 
 // bf16 C: one tile per workgroup (the stores of a tile drain while the CU's next workgroup runs its K loop); fp32 C (weight
-// gradients, split-K slabs): persistent.  gemm_variant 5 / 6 force the end-of-tile / mid-tile barrier schedule (A/B).
+// gradients, split-K slabs): persistent.  gemm_variant 5 forces the end-of-tile barrier schedule (A/B).
 template <int LAYOUT, typename TC>
 static int launch_one(const GemmArgs& a, int splits, hipStream_t st) {
   constexpr bool persist = sizeof(TC) != 2;
-  // Schedule per layout, from the in-process A/B on the BASELINE shapes (tools/gemm_ab_libs.py lib@6 lib@5): the mid-tile barrier
-  // wins 4-7 % with at least one K-major operand (NT forward, NN data gradient), loses 4-8 % with two strided ones (TN weight
-  // gradient: two transposing reads per fragment, the request burst it hides is twice as long).  gemm_variant 5 / 6 force one.
-  const bool mid = a.variant == 6 || (a.variant != 5 && LAYOUT != MTS_TN);
-  if (!mid) return launch_one_p<LAYOUT, TC, persist, false>(a, splits, st);
-  return launch_one_p<LAYOUT, TC, persist, true>(a, splits, st);
+  // Schedule per layout, from the in-process A/B on the BASELINE shapes (tools/gemm_ab_libs.py lib@0 lib@5): the mid-tile barrier
+  // wins 4-7 % with at least one K-major operand (NT forward, NN data gradient, TT).  With two strided ones (TN weight gradient:
+  // two transposing reads per fragment and a register copy where the halves are joined) it measured 4-8 % slower and, with the
+  // persistent fp32-C state on top, no longer fits the register file without spilling fragment registers in flight: TN is only
+  // built with the end-of-tile barrier.  gemm_variant 5 selects that schedule for every layout (A/B).
+  if constexpr (LAYOUT == MTS_TN) {
+    return launch_one_p<LAYOUT, TC, persist, false>(a, splits, st);
+  } else {
+    if (a.variant == 5) return launch_one_p<LAYOUT, TC, persist, false>(a, splits, st);
+    return launch_one_p<LAYOUT, TC, persist, true>(a, splits, st);
+  }
 }
 
 // called from mts_gemm (gemm.hip) when N is a multiple of 224 and the 224-wide tiling fills the CUs better

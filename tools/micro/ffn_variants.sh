@@ -1,7 +1,10 @@
 #!/bin/bash
-# Timing experiments on the fused feed-forward kernel: small libraries holding only csrc/ffn_fused.hip, one per FFN_DBG_* macro
-# (results of the DBG variants are wrong on purpose -- they take one ingredient out of the step to show what the step waits for).
-#   bash tools/micro/ffn_variants.sh && gpurun -- python tools/micro/ffn_ab_libs.py tools/ab_libs/libffn_*.so
+# Timing builds of the fused feed-forward kernel: small libraries holding only csrc/ffn_fused.hip -- the production kernel (base)
+# and the same with per-wave cycle sums (-DFFN_STAMPS: copy waves and compute waves, per step of both phases).
+#   bash tools/micro/ffn_variants.sh && gpurun -- python tools/micro/ffn_stamps.py tools/ab_libs/libffn_STAMPS.so
+#                                      gpurun -- python tools/micro/ffn_ab_libs.py tools/ab_libs/libffn_*.so
+# (The first version of the kernel also had builds with the copies / the LDS reads / the MFMAs taken out:
+#  profiles/r02_ffn_ingredients_first_version.txt.)
 set -e
 cd "$(dirname "$0")/../.."
 C=multimodaltopicsegmentation_amd/csrc
@@ -12,7 +15,7 @@ static char g_err[512];
 void mts_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap); }
 extern "C" const char* mts_last_error() { return g_err; }
 EOT
-for v in base NO_MMA NO_DMA NO_LDSREAD STAMPS "$@"; do
+for v in base STAMPS "$@"; do
   def=""; [ "$v" != base ] && def="-DFFN_DBG_$v"; [ "$v" = STAMPS ] && def="-DFFN_STAMPS"
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $def -I$C -Iinclude -shared -o tools/ab_libs/libffn_$v.so $C/ffn_fused.hip /tmp/ffn_stub.cpp &
 done
