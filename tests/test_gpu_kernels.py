@@ -118,6 +118,38 @@ def test_gemm_bf16_tile_224(ops, layout, M, N, K):
         L.check(L.lib.mts_set_option(b'gemm_tile', 0))
 
 
+@pytest.mark.parametrize('layout', ['NT', 'NN', 'TT'])
+@pytest.mark.parametrize('M,N,K', [(512, 448, 64), (512, 448, 128), (768, 1792, 1792), (1000, 224, 704)])
+def test_gemm_224_barrier_schedules_agree_bitwise(ops, layout, M, N, K):
+    """The two K-loop schedules of the 256x224 kernel (barrier in the middle of the K-tile: default for NT / NN / TT; at its end:
+    gemm_variant 5) accumulate every output element in the same order -- results must be identical bit for bit, with 1, 2 and many
+    K-tiles (prologue-only, no steady state, steady state), M tails, bf16 and fp32 C, bias + residual epilogue."""
+    from multimodaltopicsegmentation_amd import _lib as L
+    a = _rnd(M, K, seed=61).to(torch.bfloat16)
+    b = _rnd(N, K, seed=62).to(torch.bfloat16)
+    bias, res = _rnd(N, seed=63).to(DEV), _rnd(M, N, seed=64).to(torch.bfloat16).to(DEV)
+    A, Bm, code = {'NT': (a, b, L.NT), 'NN': (a, b.t().contiguous(), L.NN), 'TT': (a.t().contiguous(), b, L.TT)}[layout]
+    A, Bm = A.to(DEV), Bm.to(DEV)
+    outs = {}
+    try:
+        L.check(L.lib.mts_set_option(b'gemm_tile', 224))
+        for variant in (0, 5):
+            L.check(L.lib.mts_set_option(b'gemm_variant', variant))
+            o16 = torch.full((M, N), float('nan'), dtype=torch.bfloat16, device=DEV)
+            ops.gemm(code, A, Bm, o16, M=M, N=N, K=K, bias=bias, residual=res)
+            o32 = torch.full((M, N), float('nan'), dtype=torch.float32, device=DEV)
+            ops.gemm(code, A, Bm, o32, M=M, N=N, K=K)
+            outs[variant] = (o16.clone(), o32.clone())
+    finally:
+        L.check(L.lib.mts_set_option(b'gemm_variant', 0))
+        L.check(L.lib.mts_set_option(b'gemm_tile', 0))
+    assert torch.equal(outs[0][0].view(torch.int16), outs[5][0].view(torch.int16))
+    assert torch.equal(outs[0][1].view(torch.int32), outs[5][1].view(torch.int32))
+    assert not torch.isnan(outs[0][1]).any()
+    ref = a.double() @ b.double().t()
+    _close(outs[0][1], ref, 1e-4, 1e-4 * math.sqrt(K), f'{layout} mid-tile barrier fp32 C')
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_gemm_epilogues(ops, dtype):
     M, N, K = 192, 256, 128
