@@ -16,6 +16,7 @@ its parameters in one flat fp32 buffer (flat.py) and has two front-ends over the
   * ``.loss_and_grad()`` writes all gradients straight into the flat gradient buffer without autograd
     (native trainer, bench.py, RCCL data parallel).
 """
+import functools
 import math
 import os
 from collections import OrderedDict
@@ -74,8 +75,33 @@ class _Workspace:
         return t[:need].view(rows, cols)
 
 
+def _on_model_device(fn):
+    """Run a public entry point with the model's GPU as the current device: the kernels are launched on torch's
+    CURRENT stream (`_lib.stream_ptr`) of the CURRENT device, so a model living on cuda:1 called while cuda:0 is current would
+    otherwise enqueue on the wrong device's stream."""
+    @functools.wraps(fn)
+    def guarded(self, *args, **kwargs):
+        dev = self._flat.device
+        if dev.type != 'cuda' or torch.cuda.current_device() == dev.index:
+            return fn(self, *args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(self, *args, **kwargs)
+    guarded._mts_device_guard = True
+    return guarded
+
+
 class _TaggerBase(FlatModule):
     """Shared tail: loss kinds, decode, autograd bridge, bf16 weight mirror."""
+
+    _GUARDED_ENTRY_POINTS = ('loss_and_grad', 'loss', 'encode', 'forward')
+
+    def __init_subclass__(cls, **kw):
+        super().__init_subclass__(**kw)
+        for name in cls._GUARDED_ENTRY_POINTS:
+            fn = cls.__dict__.get(name)
+            if fn is not None and not getattr(fn, '_mts_device_guard', False):
+                setattr(cls, name, _on_model_device(fn))
+
 
     def _init_common(self, loss_fn, threshold, alpha, gamma, compute_dtype):
         if loss_fn not in LOSS_KINDS:

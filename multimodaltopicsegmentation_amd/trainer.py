@@ -150,6 +150,13 @@ class NativeTrainer:
 
     def step(self, batch):
         """One optimizer step on this rank's shard; returns the local loss (0-d tensor)."""
+        dev = self.model.flat.device
+        if dev.type == 'cuda' and torch.cuda.current_device() != dev.index:
+            with torch.cuda.device(dev):             # kernels go to the CURRENT device's current stream (taggers._on_model_device)
+                return self._step(batch)
+        return self._step(batch)
+
+    def _step(self, batch):
         m = self.model
         x, lengths, tags = batch['src_tokens'], batch['src_lengths'], batch['tgt_tokens']
         if self.world > 1:
