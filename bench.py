@@ -125,6 +125,8 @@ def infer_latency(args, model, batch, wl, world, rank):
     boundary lists, i.e. what predict.py / test_step wait for per document.  Wall-clock per call (host launch overhead included:
     at batch 1 the path is launch-bound), median / p95 over --steps calls after --warmup."""
     model.eval()
+    if getattr(args, 'graph', False):
+        model.inference_graphs = True            # Transformer_segmenter: replay forward + decode as one hipGraph per (B, L) shape
     x, lengths = batch['src_tokens'], batch['src_lengths']
     x2 = batch.get('src_tokens2')
     call = (lambda: model(x, x2, lengths)) if x2 is not None else (lambda: model(x, lengths))
@@ -143,11 +145,12 @@ def infer_latency(args, model, batch, wl, world, rank):
         print(json.dumps({'metric': 'inference latency per call (forward + decode + D2H)', 'value': 1e3 * med, 'unit': 'ms', 'p95_ms': 1e3 * p95,
                           'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'higher_is_better': False, 'dtype': args.dtype,
                           'data': 'synthetic', 'sentences_per_s': n_sent / med,
-                          'config': {'workload': f'inference: {wl}, {args.docs} document(s) x {args.seq} sentences per call'}}))
+                          'config': {'workload': f'inference: {wl}, {args.docs} document(s) x {args.seq} sentences per call' + (', hipGraph replay' if getattr(args, 'graph', False) and hasattr(model, 'inference_graphs') else '')}}))
 
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--graph', action='store_true', help='--infer: replay the transformer forward + decode as a hipGraph')
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)

@@ -64,6 +64,7 @@ class _Workspace:
 
     def __init__(self):
         self.bufs = {}
+        self.generation = 0              # bumped whenever a buffer is (re)allocated: captured graphs hold the old addresses
 
     def get(self, name, rows, cols, dtype, device):
         key = name
@@ -72,6 +73,7 @@ class _Workspace:
         if t is None or t.numel() < need or t.dtype != dtype or t.device != device:
             t = torch.empty(max(need, 1), dtype=dtype, device=device)
             self.bufs[key] = t
+            self.generation += 1
         return t[:need].view(rows, cols)
 
 
@@ -663,12 +665,68 @@ class Transformer_segmenter(_TaggerBase):
         st = self._forward_native(xs, self._prep_lengths(lengths, B, Lq, x1.device))
         return st['hidden'].view(B, Lq, -1).to(torch.float32)
 
+    # Inference at one document per call is launch-bound (a dozen kernels of a few microseconds each): with inference_graphs = True
+    # the forward + decode of a given (B, L) shape is captured once as a hipGraph (torch.cuda.CUDAGraph: the kernels are enqueued
+    # on torch's current stream, which is the capturing stream inside the capture) and replayed on static input / output buffers.
+    # Same kernels, same order, same buffers: bitwise the eager results.  Eval mode, single-tensor input only; anything else, and
+    # every shape after the 16th, takes the eager path.
+    inference_graphs = False
+
+    def _graph_entry(self, xs, li32, threshold):
+        th = float(self.th if self.th is not None else threshold)
+        key = (tuple(xs.shape), xs.dtype, th, self._ws.generation, self._flat.data_ptr())
+        ent = self._graphs.get(key) if hasattr(self, '_graphs') else None
+        if ent is not None:
+            return ent
+        if not hasattr(self, '_graphs'):
+            self._graphs = {}
+        if len(self._graphs) >= 16:
+            return None
+        B, Lq = xs.shape[0], xs.shape[1]
+        dev = xs.device
+        xs_s, li_s = torch.empty_like(xs), torch.empty_like(li32)
+        tags = torch.empty(B, Lq, dtype=torch.uint8, device=dev)
+        xs_s.copy_(xs)
+        li_s.copy_(li32)
+
+        def run():
+            st = self._forward_native(xs_s, li_s)
+            ops.greedy_decode(st['scores'], li_s, th, tags)
+            return st['scores']
+        self._weights()                                   # the bf16 mirror is refreshed OUTSIDE the graph (a cast inside would replay forever)
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):                     # warm-up: buffer allocation, first-launch attribute calls
+            run()
+        cur.wait_stream(side)
+        key = (tuple(xs.shape), xs.dtype, th, self._ws.generation, self._flat.data_ptr())       # (the warm-up may have grown the workspace)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            scores = run()
+        ent = self._graphs[key] = (g, xs_s, li_s, scores, tags)
+        return ent
+
     def forward(self, xs, lenghts, threshold=0.4):
         """models/CRF.py:597-610 -> (scores [B,L,n_out], list of per-document bool lists)."""
         L.require_gpu()
-        x1, _, B, Lq, _ = self._split_input(xs)
+        x1, x2, B, Lq, _ = self._split_input(xs)
         li32 = self._prep_lengths(lenghts, B, Lq, x1.device)
         with torch.no_grad():
+            ent = None
+            if self.inference_graphs and not self.training and x2 is None and torch.is_tensor(xs) and xs.dtype == torch.float32 and xs.is_contiguous():
+                ent = self._graph_entry(xs, li32, threshold)
+            if ent is not None:
+                g, xs_s, li_s, scores_s, tags_s = ent
+                self._weights()
+                xs_s.copy_(xs)
+                li_s.copy_(li32)
+                g.replay()
+                scores = scores_s.clone()
+                tags_h = tags_s.cpu().numpy().astype(bool)
+                L.check_async()
+                lens = [int(v) for v in (lenghts.tolist() if lenghts is not None else [Lq] * B)]
+                return scores, [tags_h[i, :lens[i]].tolist() for i in range(B)]
             st = self._forward_native(xs, li32)
             scores = st['scores'].clone()
             tags = self._decode(scores, li32, lenghts, threshold)

@@ -641,3 +641,40 @@ def test_text_segmenter_option_matrix(arch):
         res = ts.test_step(batch, 0)
         assert all(np.isfinite(float(v)) for v in res.values())
         assert [len(t) for t in ts.predict_step(batch, 0)] == [30, 12, 1, 22]
+
+
+# ------------------------------------------------------------------------------------------------ inference as a replayed hipGraph
+@pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
+def test_inference_graph_replay_is_bitwise_the_eager_forward(dtype):
+    """inference_graphs = True: forward + decode of a (B, L) shape captured once and replayed on static buffers -- same kernels,
+    same order: scores and boundary lists identical to the eager call, for new inputs, a second shape, and after the weights moved
+    (the bf16 mirror is refreshed outside the graph)."""
+    from multimodaltopicsegmentation_amd.taggers import Transformer_segmenter
+    D = 512
+    m = Transformer_segmenter(2, D, 256, num_layers=2, nheads=4, loss_fn='FocalLoss', window_size=6, compute_dtype=dtype, seed=9).to(DEV).eval()
+    g = torch.Generator().manual_seed(12)
+
+    def batch(B, Lq):
+        lengths = torch.randint(3, Lq + 1, (B,), generator=g)
+        lengths[0] = Lq
+        return torch.randn(B, Lq, D, generator=g).to(DEV), lengths
+
+    def both(x, lengths):
+        m.inference_graphs = False
+        s0, t0 = m(x, lengths)
+        m.inference_graphs = True
+        s1, t1 = m(x, lengths)
+        assert torch.equal(s0, s1) and t0 == t1
+        return s0
+
+    x, l = batch(1, 300)
+    both(x, l)
+    x2, l2 = batch(1, 300)                       # same shape, other data: replay on the static buffers
+    s_a = both(x2, l2)
+    both(*batch(3, 77))                          # second shape: second graph
+    assert len(m._graphs) == 2
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.01 * torch.randn(p.shape, generator=g).to(DEV))      # weights move (as an optimizer step would)
+    s_b = both(x2, l2)
+    assert not torch.equal(s_a, s_b)
