@@ -76,7 +76,7 @@ def test_fused_block_rejects_what_it_does_not_cover():
 
 
 @pytest.mark.parametrize('packed', [False, True])
-def test_transformer_step_is_bitwise_the_same_with_and_without_the_fused_block(packed):
+def test_transformer_step_is_bitwise_the_same_with_and_without_the_fused_block(packed, monkeypatch):
     """Model level: loss, scores and every gradient of a bf16 Transformer_segmenter (d = 512, ff = 256, ragged documents) agree
     bit for bit whether the layer runs the fused block or the GEMM pairs."""
     from multimodaltopicsegmentation_amd.taggers import Transformer_segmenter
@@ -91,10 +91,16 @@ def test_transformer_step_is_bitwise_the_same_with_and_without_the_fused_block(p
     x, y = x.to(DEV), y.to(DEV)
     m = Transformer_segmenter(2, D, 256, num_layers=2, nheads=4, loss_fn='FocalLoss', window_size=6, compute_dtype='bf16', seed=5).to(DEV)
     m.pack_rows = packed
+    m.fuse_ffn_min_rows = 0                      # (the model fuses from 12288 rows on, where 64-row workgroups fill the chip)
+    from multimodaltopicsegmentation_amd import ops
+    calls = {'n': 0}
+    real = ops.ffn_fwd
+    monkeypatch.setattr(ops, 'ffn_fwd', lambda *a, **k: (calls.__setitem__('n', calls['n'] + 1), real(*a, **k))[1])
     out = []
     for fuse in (True, False):
         m.fuse_ffn = fuse
         loss, sc = m.loss_and_grad(x, lengths, y, True)
+        assert calls['n'] == (2 if fuse else 2)          # two layers through the fused kernel in the first pass, none added in the second
         out.append((loss.item(), sc.float().clone(), m.grad_flat().clone()))
     assert out[0][0] == out[1][0]
     assert torch.equal(out[0][1], out[1][1])
