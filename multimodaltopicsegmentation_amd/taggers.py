@@ -602,7 +602,7 @@ class Transformer_segmenter(_TaggerBase):
         self._drop_calls += 1
         return (torch.initial_seed() * 1000003 + self._drop_calls * 7919) & 0x7FFFFFFFFFFFFFFF
 
-    overlap_wgrad = False    # True: +2 % step throughput at the BASELINE shape (2.70 -> 2.64 ms), but co-running kernels stretch each
+    overlap_wgrad = os.environ.get('MTS_OVERLAP_WGRAD', '0') == '1'    # True: +2 % step throughput at the BASELINE shape (2.70 -> 2.64 ms in round 1), but co-running kernels stretch each
                              # other, so per-kernel timings (bench.py's roofline) stop describing a kernel; off by default
 
     def _side_stream(self, dev):
