@@ -119,7 +119,7 @@ def test_gemm_bf16_tile_224(ops, layout, M, N, K):
 
 
 @pytest.mark.parametrize('layout', ['NT', 'NN', 'TT'])
-@pytest.mark.parametrize('M,N,K', [(512, 448, 64), (512, 448, 128), (768, 1792, 1792), (1000, 224, 704)])
+@pytest.mark.parametrize('M,N,K', [(512, 448, 64), (512, 448, 128), (512, 448, 192), (256, 224, 256), (768, 1792, 1792), (1000, 224, 704)])
 def test_gemm_224_barrier_schedules_agree_bitwise(ops, layout, M, N, K):
     """The two K-loop schedules of the 256x224 kernel (barrier in the middle of the K-tile: default for NT / NN / TT; at its end:
     gemm_variant 5) accumulate every output element in the same order -- results must be identical bit for bit, with 1, 2 and many
