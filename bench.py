@@ -148,6 +148,32 @@ def infer_latency(args, model, batch, wl, world, rank):
                           'config': {'workload': f'inference: {wl}, {args.docs} document(s) x {args.seq} sentences per call' + (', hipGraph replay' if getattr(args, 'graph', False) and hasattr(model, 'inference_graphs') else '')}}))
 
 
+def self_launch(n, rehearsal):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start N fresh ranks (one process per GPU) under
+    torch.distributed.run on 127.0.0.1 with the same arguments and return their exit code.  Rank 0's JSON line goes straight to the
+    inherited stdout.  This parent never initialises the GPU (torch.cuda.device_count() only counts devices), so the children are
+    ordinary child processes of a GPU-free launcher."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if rehearsal:
+        if n > 6:                                  # a GPU box allows 6 processes on its card at once
+            print(f'bench.py: MTS_BENCH_REHEARSAL runs every rank on cuda:0; at most 6 ranks, got --gpus {n}', file=sys.stderr)
+            return 2
+    elif have < n:
+        print(f'bench.py: --gpus {n} requested but {have} GPU(s) are visible on this node', file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--graph', action='store_true', help='--infer: replay the transformer forward + decode as a hipGraph')
@@ -172,14 +198,18 @@ def main():
     args = ap.parse_args()
 
     import torch.distributed as dist
+    # MTS_BENCH_REHEARSAL=1: every rank on cuda:0 over gloo -- exercises the N>1 code path (sharding, gradient-ready hooks,
+    # async exchange, max-over-ranks timing) on a one-GPU box; the numbers it prints mean nothing
+    rehearsal = os.environ.get('MTS_BENCH_REHEARSAL') == '1'
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` by itself (the reference's entry is a plain Trainer(gpus=N), train_fit.py:284-296): this
+        # process never touches the GPU; it starts N fresh ranks under torch.distributed.run and exits with their code
+        raise SystemExit(self_launch(args.gpus, rehearsal))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)')
-    # MTS_BENCH_REHEARSAL=1: every rank on cuda:0 over gloo -- exercises the N>1 code path (sharding, gradient-ready hooks,
-    # async exchange, max-over-ranks timing) on a one-GPU box; the numbers it prints mean nothing
-    rehearsal = os.environ.get('MTS_BENCH_REHEARSAL') == '1'
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}, or without torch.distributed.run')
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -190,6 +220,16 @@ def main():
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=device)      # backend "nccl" is RCCL on ROCm
+    # MTS_BENCH_SINGLE_RANK_DP=1: a process group of ONE rank over RCCL and the trainer's overlapped exchange path forced on -- what
+    # the N > 1 step costs on this GPU besides the wire time (hook order, per-projection weight gradients, collective launches)
+    single_rank_dp = world == 1 and os.environ.get('MTS_BENCH_SINGLE_RANK_DP') == '1'
+    if single_rank_dp:
+        import socket
+        s_ = socket.socket()
+        s_.bind(('127.0.0.1', 0))
+        port_ = s_.getsockname()[1]
+        s_.close()
+        dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port_}', rank=0, world_size=1, device_id=device)
 
     from multimodaltopicsegmentation_amd import ops
     from multimodaltopicsegmentation_amd.rnn_taggers import BiLSTM, BiLSTMLateFusion, BiRnnCrf
@@ -238,7 +278,9 @@ def main():
     else:
         cfg_label = 'variant (not a BASELINE.json configuration)'
     model = model.to(device)
-    trainer = NativeTrainer(model, lr=1e-3, optimizer='Adam')
+    trainer = NativeTrainer(model, lr=1e-3, optimizer='Adam', always_hook=single_rank_dp)
+    if single_rank_dp:
+        cfg_label = 'variant (data-parallel step path forced on in a one-rank RCCL group): ' + cfg_label
     batch = synthetic_batch(args.docs, args.seq, D, rank, device, D2, ragged=args.ragged)
     if args.no_pack and hasattr(model, 'pack_rows'):
         model.pack_rows = False
@@ -314,7 +356,7 @@ def main():
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'{cfg_label}: {wl}, {args.docs} docs x {args.seq} sentences per GPU, '
                                    f'fwd+bwd+Adam(eps 1e-7), inputs resident in HBM' + (', ragged lengths U{L/4..L}' + (' (padded rows kept)' if args.no_pack else ' (packed)') if args.ragged else ''),
-                       'global_batch_docs': world * args.docs, 'sentences_per_doc': args.seq, 'parallelism': f'dp{world} (document-sharded, RCCL all-reduce)'},
+                       'global_batch_docs': world * args.docs, 'sentences_per_doc': args.seq, 'parallelism': f'dp{world} (document-sharded, ' + ('gloo all-reduce, every rank on cuda:0: REHEARSAL, numbers mean nothing)' if rehearsal else 'RCCL all-reduce)')},
             'final_loss': loss_val,
         }
         if sustained is not None:
@@ -386,7 +428,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.arch == 'transformer':
             out['cpu_baseline'] = cpu_baseline(args, D, ff, heads, window, n_layers)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or single_rank_dp:
         dist.destroy_process_group()
 
 

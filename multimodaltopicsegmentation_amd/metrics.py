@@ -1,9 +1,22 @@
 """Segmentation metrics used by ``TextSegmenter.test_step`` (reference: models/lightning_model.py:16-152).
 
-``segeval`` (third party, pinned 2.0.11 in requirements.txt:4) is what the reference calls for Pk / WindowDiff;
-it is not installed here, so the published definitions are implemented directly (Beeferman et al. 1999; Pevzner &
-Hearst 2002) with segeval's default window k = round(mean reference segment mass / 2).  If ``segeval`` is
-importable it is used instead, so results are identical to the reference's on a machine that has it.
+``segeval`` (third party, pinned 2.0.11 in requirements.txt:4) is what the reference calls for Pk / WindowDiff / B; it is
+not installed here and not part of the reference tree.  If it is importable it is used, so results are the reference's own
+on a machine that has it.  Otherwise Pk and WindowDiff follow segeval 2.0.11's published behaviour -- PARITY UNPINNED for
+exactly these conventions (nothing here can execute segeval; tests/test_product_host_cpu.py holds hand-computed cases):
+
+  * masses -> one segment index per unit; hypothesis and reference must cover the same number of units;
+  * default window k = int(round(mean reference mass / 2)) with python's round (half to even; segeval rounds a Decimal
+    the same way), and k = 2 whenever that is below 2;
+  * N - k windows, window i spans units i .. i + k;
+  * Pk (Beeferman et al. 1999): fraction of windows whose two end units lie in the same segment in exactly one of the
+    two segmentations;  WindowDiff (Pevzner & Hearst 2002): fraction of windows in which the two segmentations place a
+    different NUMBER of boundaries (segeval's default lamprier_et_al_2007_fix=False: no phantom padding);
+  * the error itself is returned (one_minus=False), as a float (segeval returns Decimal; the reference casts to float);
+  * a document not longer than the window has no windows: 0.0 here (segeval's Pk also returns 0 there).
+
+WinPR is pure Python upstream and pinned by fixture g16.  B (boundary edit distance, Fournier 2013) stays a documented
+raise without segeval: its transposition weighting lives in segeval's source, which cannot be consulted or executed here.
 """
 import numpy as np
 

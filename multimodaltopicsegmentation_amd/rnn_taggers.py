@@ -286,7 +286,11 @@ class BiLSTM(_RnnTaggerBase):
 
 class BiLSTMLateFusion(_RnnTaggerBase):
     """models/CRF.py:371-479: two independent RNNs, plain concat (there is no gate in the reference), one head."""
-    concurrent_encoders = True       # model1 / model2 on two HIP streams (bitwise the same results; off under a data-parallel hook)
+    concurrent_encoders = True       # model1 / model2 on two HIP streams (bitwise the same results).  Under a data-parallel hook too:
+                                     # model2's spans are announced from inside `with stream(side)`, so the collective is issued
+                                     # with the side stream current and waits on exactly the kernels that wrote the span (RCCL and
+                                     # gloo both order a collective behind the stream that is current when it is issued); the host
+                                     # order of the announcements -- model2's layers, then model1's -- is the same on every rank
 
     def _side_stream(self, dev):
         s = getattr(self, '_enc_stream', None)
@@ -322,7 +326,7 @@ class BiLSTMLateFusion(_RnnTaggerBase):
         B, H = xa.shape[0], self._hp
         li32 = self._prep_lengths(lengths, B, Lq, x1.device)
         # the two encoders are independent and each recurrence occupies a few dozen CUs: run the second one on a side stream
-        side = self._side_stream(x1.device) if (self.concurrent_encoders and self._grad_hook is None) else None
+        side = self._side_stream(x1.device) if self.concurrent_encoders else None
         if side is not None:
             main = torch.cuda.current_stream(x1.device)
             self._weights()                            # a stale bf16 mirror is re-cast HERE, on the main stream, ahead of both encoders
@@ -365,7 +369,7 @@ class BiLSTMLateFusion(_RnnTaggerBase):
             if st['m1'] is not None:
                 ops.dropout_bwd(d1, d1, st['m1'], self.dropout_out)
                 ops.dropout_bwd(d2, d2, st['m2'], self.dropout_out)
-            side = self._side_stream(dev) if (self.concurrent_encoders and self._grad_hook is None) else None
+            side = self._side_stream(dev) if self.concurrent_encoders else None
             if side is not None:
                 main = torch.cuda.current_stream(dev)
                 self._weights()                        # see _fwd: never let the side stream be the one that refreshes the mirror

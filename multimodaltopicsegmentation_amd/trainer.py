@@ -42,7 +42,8 @@ def local_loss_count(model, batch):
 
 
 class NativeTrainer:
-    def __init__(self, model, lr=1e-3, optimizer='Adam', process_group=None, token_weighted=False, grad_exchange_dtype='fp32'):
+    def __init__(self, model, lr=1e-3, optimizer='Adam', process_group=None, token_weighted=False, grad_exchange_dtype='fp32',
+                 always_hook=False):
         """model: a tagger from taggers.py / rnn_taggers.py (or a TextSegmenter, whose .model is used).
 
         token_weighted: the reference's loss is a mean over the LOCAL batch's valid sentences (models/CRF.py:352), so plain data
@@ -52,7 +53,11 @@ class NativeTrainer:
 
         grad_exchange_dtype: 'fp32' | 'bf16'.  bf16 halves the bytes on the xGMI ring (84.5 -> 42.3 MB per step for the 1-layer
         band encoder); each rank's contribution is rounded to bf16 (relative 2^-9) and summed in bf16 by the collective, so the
-        exchanged sum is within 2^-8 * sum_r |g_r| of the fp32 one (tests/test_distributed_cpu.py)."""
+        exchanged sum is within 2^-8 * sum_r |g_r| of the fp32 one (tests/test_distributed_cpu.py).
+
+        always_hook: take the overlapped exchange path (gradient-ready hooks -> asynchronous all-reduce per span) even in a
+        process group of ONE rank.  Measurement aid: the N > 1 step path -- hook order, per-projection release, collective
+        launches, stream waits -- on a single GPU (bench.py MTS_BENCH_SINGLE_RANK_DP=1); needs an initialised process group."""
         # a TextSegmenter wraps the tagger in .model; a bare tagger may itself own a parameter container called "model"
         self.model = model.model if hasattr(model, 'training_step') else model
         self.lr, self.kind = float(lr), optimizer
@@ -62,6 +67,7 @@ class NativeTrainer:
         self._m = self._v = None
         self._comm_stream = None
         self.token_weighted = bool(token_weighted)
+        self.always_hook = bool(always_hook) and dist.is_available() and dist.is_initialized()
         if grad_exchange_dtype not in ('fp32', 'bf16'):
             raise ValueError("grad_exchange_dtype must be 'fp32' or 'bf16'")
         self.exchange_bf16 = grad_exchange_dtype == 'bf16'
@@ -164,7 +170,7 @@ class NativeTrainer:
             self._check_same_length(x.shape[1])
         self._last_L = x.shape[1]
         m.loss_grad_scale = self.exchange_weight(batch)
-        overlapped = self.world > 1 and getattr(m, 'grad_hooks_cover_all', False)
+        overlapped = (self.world > 1 or self.always_hook) and getattr(m, 'grad_hooks_cover_all', False)
         self._pending = []
         m._grad_hook = self._on_grads_ready if overlapped else None
         if batch.get('src_tokens2') is not None and hasattr(m, '_rnn2'):

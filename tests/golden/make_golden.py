@@ -43,7 +43,7 @@ _pl.LightningModule = _LM
 sys.modules['pytorch_lightning'] = _pl
 sys.modules['segeval'] = types.ModuleType('segeval')
 
-from models.lightning_model import TextSegmenter, get_boundaries  # noqa: E402
+from models.lightning_model import TextSegmenter, get_boundaries, WinPR  # noqa: E402
 from models.CRF import CRF  # noqa: E402
 from models.NeuralArchitectures import RNN, create_mask  # noqa: E402
 from models.focal_loss import sigmoid_focal_loss  # noqa: E402
@@ -593,13 +593,58 @@ def g15_adjacent_encoders():
     record('unidirectional.loss', lambda: tagger(bidirectional=False).model.loss(x, l, y))
     record('unidirectional.forward', lambda: tagger(bidirectional=False).model(x, l))
     record('cosine.training_step', lambda: tagger(cosine_loss=True).training_step({'src_tokens': x, 'tgt_tokens': y, 'src_lengths': l}, 0))
+    # BiLSTMRestrictedMHA (CRF.py:636-684) builds its attention from models/longformer_noffn.py, which the reference tree does not
+    # ship: `import models.CRF` itself fails with ModuleNotFoundError on an unmodified checkout.  THAT is the record (this
+    # generator can only import models.CRF at all because it registers an empty stand-in module, so whatever a constructor call
+    # raised here would describe the stand-in, not the reference -- round 2 stored exactly that artefact; dropped).
     out['longformer_noffn_source_present'] = np.array(int(os.path.exists(os.path.join(REF, 'models', 'longformer_noffn.py'))))
-    record('restricted_mha.ctor', lambda: TextSegmenter(2, 16, 8, num_layers=1, architecture='BiLSTMRestrictedMHA', loss_fn='FocalLoss'))
+    importers = sorted(f for f in os.listdir(os.path.join(REF, 'models')) if f.endswith('.py')
+                       and any(ln.startswith(('from models.longformer_noffn import', 'import models.longformer_noffn'))
+                               for ln in open(os.path.join(REF, 'models', f)).read().splitlines()))
+    out['longformer_noffn_imported_at_module_level_by'] = np.array(','.join(importers))
+    print('longformer_noffn present:', out['longformer_noffn_source_present'], 'imported by:', importers)
     save('g15_adjacent_encoders', **out)
 
 
+def g16_winpr():
+    """WinPR of the reference itself (lightning_model.py:57-124; pure Python, no third-party call): random segmentations at several
+    window sizes, k larger than the document (every start index negative: python's wrap-around slicing feeds the 'previous span'
+    test), k = 1, an empty hypothesis (ZeroDivisionError caught upstream -> (0, 0, 0)), all-boundary inputs, and the two inputs on
+    which the reference RAISES ZeroDivisionError out of the function (recall with TP = FN = 0; f1 with precision = recall = 0).
+    Stored flat: case c uses ref/hyp[off[c]:off[c+1]], k[c]; result prf[c] (nan where it raised), raised[c] = exception name."""
+    rng = np.random.default_rng(1616)
+    cases = []
+    for N, k, pr, ph in [(40, 10, .15, .15), (40, 3, .3, .1), (25, 1, .2, .2), (7, 10, .3, .3), (12, 12, .25, .4), (60, 5, .05, .3),
+                         (33, 7, .5, .5), (90, 10, .1, .1), (5, 2, .4, .4), (1, 10, 1., 1.), (18, 4, .2, .6), (64, 16, .1, .2)]:
+        cases.append(((rng.random(N) < pr).astype(int).tolist(), (rng.random(N) < ph).astype(int).tolist(), k))
+    r = (rng.random(30) < .2).astype(int).tolist()
+    cases.append((r, [0] * 30, 10))                          # empty hypothesis
+    cases.append(([1] * 15, [1] * 15, 4))                    # every position a boundary
+    cases.append((r, list(r), 10))                           # perfect hypothesis
+    cases.append(([0] * 20, [0] * 20, 10))                   # nothing anywhere
+    cases.append(([0] * 20, [0, 0, 1] + [0] * 17, 10))       # raises: recall = 0 / 0
+    cases.append(([0, 0, 0, 0, 0, 0, 0, 0, 0, 1], [1, 0, 0, 0, 0, 0, 0, 0, 0, 0], 1))   # may raise: precision = recall = 0
+    cases.append(([0, 1, 0, 0, 1, 0], [0, 0, 1, 0, 0, 1], 2))     # near misses
+    refs, hyps, off, ks, prf, raised = [], [], [0], [], [], []
+    for ref, hyp, k in cases:
+        try:
+            res = WinPR(list(ref), list(hyp), k)
+            prf.append([float(v) for v in res])
+            raised.append('')
+        except Exception as e:  # noqa: BLE001
+            prf.append([np.nan] * 3)
+            raised.append(type(e).__name__)
+        refs += ref
+        hyps += hyp
+        off.append(len(refs))
+        ks.append(k)
+        print('winpr', len(ref), k, prf[-1], raised[-1])
+    save('g16_winpr', ref=np.array(refs, dtype=np.int64), hyp=np.array(hyps, dtype=np.int64), off=np.array(off, dtype=np.int64),
+         k=np.array(ks, dtype=np.int64), prf=np.array(prf, dtype=np.float64), raised=np.array(raised))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g7', 'g3a', 'g3b', 'g3c', 'g2', 'g4', 'g5', 'g6', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15']
+    which = sys.argv[1:] or ['g1', 'g7', 'g3a', 'g3b', 'g3c', 'g2', 'g4', 'g5', 'g6', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16']
     for w in which:
         if w == 'g1':
             g1_bilstm()
@@ -635,3 +680,5 @@ if __name__ == '__main__':
             g14_config0()
         elif w == 'g15':
             g15_adjacent_encoders()
+        elif w == 'g16':
+            g16_winpr()

@@ -55,6 +55,79 @@ def test_product_get_boundaries_matches_reference_fixture():
         assert metrics.get_boundaries(g[f'b{i}'].tolist()) == g[f'm{i}'].tolist()
 
 
+def test_product_winpr_matches_the_reference_on_every_recorded_case():
+    """lightning_model.py:57-124 (pure Python upstream, so the reference itself produced g16): several k, k larger than the
+    document (python's wrap-around slices feed the previous-span test), k = 1, empty hypothesis -> (0, 0, 0), all-boundary inputs,
+    and the inputs on which the reference raises ZeroDivisionError out of the function -- the product raises the same."""
+    from multimodaltopicsegmentation_amd import metrics
+    g = H.load('g16_winpr')
+    off, n_raised = g['off'], 0
+    assert len(g['k']) >= 19
+    for c in range(len(g['k'])):
+        ref, hyp, k = g['ref'][off[c]:off[c + 1]].tolist(), g['hyp'][off[c]:off[c + 1]].tolist(), int(g['k'][c])
+        if str(g['raised'][c]):
+            assert str(g['raised'][c]) == 'ZeroDivisionError'
+            with pytest.raises(ZeroDivisionError):
+                metrics.WinPR(ref, hyp, k)
+            n_raised += 1
+            continue
+        got = metrics.WinPR(ref, hyp, k)
+        assert [float(v) for v in got] == g['prf'][c].tolist(), (c, got, g['prf'][c])          # same integer counts, same divisions
+        assert ref == g['ref'][off[c]:off[c + 1]].tolist() and hyp == g['hyp'][off[c]:off[c + 1]].tolist()   # inputs untouched
+    assert n_raised == 2
+
+
+def test_pk_and_windowdiff_follow_the_stated_segeval_conventions_on_hand_computed_cases():
+    """PARITY UNPINNED for this convention: the reference calls the third-party segeval 2.0.11 (lightning_model.py:33-35,49-51),
+    which is not installed and not in the reference tree.  metrics.py follows segeval's PUBLISHED behaviour:
+    masses -> per-unit segment indices; window k = round-half-even(mean reference mass / 2), at least 2; N - k windows; Pk counts
+    windows whose two ends are in the same segment in exactly one of the segmentations; WindowDiff counts windows whose numbers of
+    boundaries differ.  The expected values below are worked out by hand from those rules (derivations inline), not by segeval."""
+    from fractions import Fraction as Fr
+    from multimodaltopicsegmentation_amd import metrics
+    # (hyp masses, ref masses, Pk, WD)
+    cases = [
+        # ref (3,3): mean 3, k = round(1.5) = 2.  units ref 000111, hyp 001111; windows (i, i+2), i = 0..3:
+        #   ref same? T F F T   hyp same? F F T T  -> Pk differs at i = 0, 2 -> 2/4;  boundaries ref 0 1 1 0, hyp 1 1 0 0 -> WD 2/4
+        ((2, 4), (3, 3), Fr(2, 4), Fr(2, 4)),
+        ((3, 3), (3, 3), Fr(0), Fr(0)),
+        # ref (2,2,2,2): mean 2, round(1.0) = 1 -> floor of 2.  hyp one segment of 8: every one of the 6 windows spans exactly one
+        # reference boundary and no hypothesis boundary -> both 6/6
+        ((8,), (2, 2, 2, 2), Fr(1), Fr(1)),
+        # ref (4,4): k = 2; ref 00001111, hyp (3,1,4) 00012222; i = 0..5:
+        #   Pk: ref same T T F F T T, hyp same T F F F T T -> differs at i = 1 -> 1/6
+        #   WD: ref count 0 0 1 1 0 0, hyp count 0 1 2 1 0 0 -> differs at i = 1, 2 -> 2/6  (Pk misses the doubled boundary)
+        ((3, 1, 4), (4, 4), Fr(1, 6), Fr(2, 6)),
+        # ref (5,5): mean 5, 2.5 -> round-half-even 2;  hyp (1,9): units ref 0000011111, hyp 0111111111, 8 windows (i, i+2)
+        #   ref same T T T F F T T T; hyp same F T T T T T T T -> Pk differs at 0, 3, 4 -> 3/8;  counts ref 0 0 0 1 1 0 0 0,
+        #   hyp 1 0 0 0 0 0 0 0 -> WD differs at 0, 3, 4 -> 3/8
+        ((1, 9), (5, 5), Fr(3, 8), Fr(3, 8)),
+    ]
+    for h, t, pk, wd in cases:
+        assert abs(float(metrics.pk(list(h), list(t))) - float(pk)) < 1e-15, (h, t)
+        assert abs(float(metrics.window_diff(list(h), list(t))) - float(wd)) < 1e-15, (h, t)
+    assert metrics._default_k([5, 5]) == 2 and metrics._default_k([7, 7]) == 4 and metrics._default_k([2, 2]) == 2   # 2.5 -> 2, 3.5 -> 4, floor 2
+    # through the reference's wrappers (lightning_model.py:26-55): the last position counts as a boundary while scoring, restored after
+    b, t = np.array([0, 1, 0, 0, 0, 0]), np.array([0, 0, 1, 0, 0, 0])
+    assert abs(metrics.compute_Pk(b, t) - 0.5) < 1e-15 and abs(metrics.compute_window_diff(b, t) - 0.5) < 1e-15
+    assert b.tolist() == [0, 1, 0, 0, 0, 0] and t.tolist() == [0, 0, 1, 0, 0, 0]
+    # an explicit window overrides the default (segeval.pk(h, t, window_size=k))
+    # k = 3: windows (i, i+3), i = 0..2: ref same F F F, hyp same F F T -> 1/3
+    assert abs(metrics.pk([2, 4], [3, 3], window_size=3) - Fr(1, 3)) < 1e-15
+
+
+def test_b_measure_stays_a_documented_raise_without_segeval():
+    """lightning_model.py:126-152 is four segeval calls (boundary_confusion_matrix n_t=4, precision, recall, boundary_similarity
+    n_t=10): boundary edit distance with near-miss transpositions whose weighting lives in segeval's source, which is neither
+    installed nor in the reference tree.  A re-derivation would print numbers that look like the reference's without any way to
+    check them here, so the product says so instead."""
+    from multimodaltopicsegmentation_amd import metrics
+    if metrics._segeval is not None:
+        pytest.skip('segeval is installed: B_measure delegates to it')
+    with pytest.raises(NotImplementedError, match='segeval'):
+        metrics.B_measure(np.array([0, 1, 0, 0]), np.array([0, 0, 1, 0]))
+
+
 # ------------------------------------------------------------------------------------------------ a5: RNN._reinitialize
 @pytest.mark.parametrize('arch', ['BiLSTM', 'BiLSTMLateFusion', 'biLSTMCRF'])
 @pytest.mark.parametrize('hidden', [32, 25])
@@ -107,7 +180,11 @@ def test_adjacent_encoder_options_are_dead_in_the_reference_and_rejected_here():
     assert str(g['unidirectional.loss.type']) == 'TypeError' and str(g['unidirectional.forward.type']) == 'TypeError'
     assert 'PackedSequence' in str(g['unidirectional.loss.msg'])
     assert str(g['cosine.training_step.type']) == 'KeyError' and 'src_segments' in str(g['cosine.training_step.msg'])
-    assert int(g['longformer_noffn_source_present']) == 0 and str(g['restricted_mha.ctor.type']) != ''
+    # BiLSTMRestrictedMHA: the source its attention comes from is not in the reference tree, and a module-level import of it sits in
+    # RestrictedTransformerLayer.py -- the record is that fact (round 2 stored the exception of the generator's own stand-in class)
+    assert int(g['longformer_noffn_source_present']) == 0
+    assert 'RestrictedTransformerLayer.py' in str(g['longformer_noffn_imported_at_module_level_by']).split(',')
+    assert 'restricted_mha.ctor.type' not in g
     with pytest.raises(NotImplementedError, match='GRU'):
         TextSegmenter(2, 16, 8, architecture='BiLSTM', loss_fn='FocalLoss', LSTM=False)
     with pytest.raises(NotImplementedError, match='unidirectional'):
