@@ -15,6 +15,12 @@
  *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
  *  - row-major tensors, leading dimensions in ELEMENTS;
  *  - return value: 0 = MTS_OK, otherwise an mts_status; mts_last_error() gives a message (thread local);
+ *  - Threads: every entry point may be called from any host thread, concurrently, on different streams.  The library keeps no
+ *    mutable process-wide state that influences results or kernel choice: mts_last_error() and the tuning switches of
+ *    mts_set_option() are PER HOST THREAD (a switch set by one thread applies to the calls that thread issues, and only
+ *    those -- note that torch's autograd runs backward nodes on its own thread), mts_gemm_last_plan() reports the calling
+ *    thread's most recent mts_gemm.  The only shared words are idempotent "function attribute already set" flags
+ *    (atomics) and the sticky device-error word of mts_async_status();
  *  - "act dtype" = the arithmetic/storage type of activations: MTS_F32 (parity mode, fp32 everywhere) or
  *    MTS_BF16 (bf16 storage + MFMA, fp32 accumulate/statistics).  Parameters and gradients are always fp32.
  */
@@ -74,8 +80,12 @@ int mts_set_option(const char* key, int value);
  * last poll (mts_last_error() says which).  mts_lstm_fwd / mts_lstm_bwd poll first themselves, so a training loop sees the error
  * at the next step at the latest; a host that has synchronised (decode, checkpoint) calls this.  Reading clears. */
 int mts_async_status(void);
-/* tile width (128 | 224 | 256) and K split the cost model chose for the most recent bf16 mts_gemm (bench / profiling labels) */
+/* tile width (128 | 224 | 256) and K split the cost model chose for the calling thread's most recent bf16 mts_gemm (bench / profiling labels) */
 int mts_gemm_last_plan(int* tile, int* splits);
+/* The planner by itself (pure host code, no device call): the tile width and K split mts_gemm WOULD use for this call under the
+ * calling thread's options; workspace_bytes = 0 means "no split-K workspace".  tile / splits may be NULL. */
+int mts_gemm_plan(int a_dtype, int c_dtype, int layout, int M, int N, int K, unsigned epilogue, size_t workspace_bytes,
+                  int* tile, int* splits);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense projection GEMM (MFMA for bf16, exact-fp32 VALU kernel for parity mode).

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void band_bwd_kv_kernel(const BandArgs a) {
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-static int g_band_mfma = 1;           // mts_set_option("band_mfma", 0) forces the generic kernels (A/B testing)
+static thread_local int g_band_mfma = 1;           // mts_set_option("band_mfma", 0) forces the generic kernels (A/B testing)
 void mts_band_set_mfma(int on) { g_band_mfma = on; }
 
 extern "C" int mts_band_slots(int radius) { return band_slots(radius); }

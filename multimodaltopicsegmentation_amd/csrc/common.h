@@ -1,5 +1,6 @@
 // Shared device/host helpers for the gfx950 kernels of libmts_hip.so.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

@@ -383,12 +383,12 @@ static int ffn_launch(bool bwd, hipStream_t st, const FfnArgs& a0) {
   const int grid = ceil_div(a.M, FF_BM);
   if (bwd) {
     auto k = ffn_fused_kernel<true>;
-    static bool attr = false;
+    static std::atomic<bool> attr{false};
     if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS) != hipSuccess) { mts_set_error("ffn_fused: cannot reserve %d bytes of LDS", FF_LDS); return MTS_ERR_LAUNCH; } attr = true; }
     hipLaunchKernelGGL(k, dim3(grid), dim3(FF_THREADS), FF_LDS, st, a);
   } else {
     auto k = ffn_fused_kernel<false>;
-    static bool attr = false;
+    static std::atomic<bool> attr{false};
     if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS) != hipSuccess) { mts_set_error("ffn_fused: cannot reserve %d bytes of LDS", FF_LDS); return MTS_ERR_LAUNCH; } attr = true; }
     hipLaunchKernelGGL(k, dim3(grid), dim3(FF_THREADS), FF_LDS, st, a);
   }

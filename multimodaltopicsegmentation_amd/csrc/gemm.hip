@@ -14,6 +14,7 @@
 // The accumulator tile is computed TRANSPOSED (the W fragment is the MFMA A operand) so that each lane
 // ends up with 4 consecutive output columns of one row: bias/residual/aux/C are accessed as 8/16-byte
 // vectors in the epilogue.
+#include <atomic>
 #include <algorithm>
 #include <math.h>
 #include <stdlib.h>
@@ -661,14 +662,16 @@ extern "C" int mts_cast(void* stream, int dst_dtype, const float* src, void* dst
 int mts_launch_gemm256(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st);   // gemm256.hip
 int mts_launch_gemm224(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st);   // gemm224.hip
 
-static int g_gemm_glds = -1;
-static int g_tile_mode = -1;
-static int g_force_splits = 0;
-static int g_tile_order = 1;
-static int g_gemm_deep = 1;      // "gemm_deep" = 0: never use the four-buffer copy pipeline of the 128x128 kernel (A/B testing)
-static int g_chain = 0;          // "gemm_chain" = 1: split-K of the 128x128 kernel accumulates in place (no slabs, no reduce launch); measured
+// Tuning / A-B switches and the last-plan record are PER HOST THREAD (include/mts.h "Threads"): mts_set_option from one thread never
+// changes the plan of a GEMM another thread is issuing, and mts_gemm_last_plan reports the calling thread's own most recent call.
+static thread_local int g_gemm_glds = -1;
+static thread_local int g_tile_mode = -1;
+static thread_local int g_force_splits = 0;
+static thread_local int g_tile_order = 1;
+static thread_local int g_gemm_deep = 1;      // "gemm_deep" = 0: never use the four-buffer copy pipeline of the 128x128 kernel (A/B testing)
+static thread_local int g_chain = 0;          // "gemm_chain" = 1: split-K of the 128x128 kernel accumulates in place (no slabs, no reduce launch); measured
                                  // SLOWER (532 vs 465 us on the QKV weight gradient: one agent-scope release per workgroup writes the L2 back)
-static int g_last_tile = 0, g_last_splits = 0;   // what the planner chose for the most recent bf16 mts_gemm (bench.py labels)
+static thread_local int g_last_tile = 0, g_last_splits = 0;   // what the planner chose for the most recent bf16 mts_gemm (bench.py labels)
 
 extern "C" int mts_gemm_last_plan(int* tile, int* splits) {
   if (tile) *tile = g_last_tile;
@@ -677,9 +680,9 @@ extern "C" int mts_gemm_last_plan(int* tile, int* splits) {
 }
 
 void mts_band_set_mfma(int on);   // band_attn.hip
-static int g_f32_mfma = 1;                   // fp32 (parity mode) GEMM on v_mfma_f32_16x16x4_f32; 0 = VALU kernel
-static int g_big_min_k = 256;                // smallest K the big-tile kernels are considered for ("gemm_big_min_k")
-static int g_gemm_variant = 0;               // A/B switch of the big-tile kernels (GemmArgs::variant)
+static thread_local int g_f32_mfma = 1;                   // fp32 (parity mode) GEMM on v_mfma_f32_16x16x4_f32; 0 = VALU kernel
+static thread_local int g_big_min_k = 256;                // smallest K the big-tile kernels are considered for ("gemm_big_min_k")
+static thread_local int g_gemm_variant = 0;               // A/B switch of the big-tile kernels (GemmArgs::variant)
 void mts_lstm_pair_set_spin_limit(int n);   // lstm_pair.hip
 void mts_lstm_pair_set_max_pairs(int n);
 extern "C" int mts_set_option(const char* key, int value) {
@@ -716,15 +719,75 @@ static void launch_bf16(const GemmArgs& a, int splits, hipStream_t st) {
     const bool deep = g_gemm_deep && (size_t)nt * splits <= 256 && a.ksplit >= 4 * BK;
     b.nbuf = deep ? 4 : 2;
     auto k = gemm_bf16_kernel<LAYOUT, TC, true>;
-    static bool attr_set = false;
-    if (deep && !attr_set) {
+    static std::atomic<bool> attr_set{false};      // idempotent, process-wide: two threads racing here set the same attribute twice
+    if (deep && !attr_set.load(std::memory_order_acquire)) {
       if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES) != hipSuccess) b.nbuf = 2;
-      else attr_set = true;
+      else attr_set.store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(k, dim3(nt, 1, splits), dim3(256), (b.nbuf == 4 ? 8 : 4) * TILE_BYTES, st, b);
   } else {
     hipLaunchKernelGGL((gemm_bf16_kernel<LAYOUT, TC, false>), dim3(nt, 1, splits), dim3(256), 4 * TILE_BYTES, st, a);
   }
+}
+
+// Planner of the bf16 path (pure host code, no device call): which kernel and which K split mts_gemm uses for a shape under the
+// CALLING THREAD's options.  use256: 0 = 128x128 kernel, 1 = 256x256, 2 = 256x224 (N a multiple of 224: d = 1792 projections).
+static void plan_bf16(int c_dtype, int layout, int M, int N, int K, unsigned epilogue, bool has_workspace, size_t workspace_bytes,
+                      int* use256_out, int* splits_out) {
+  // Plan: tile size (128x128, 2 workgroups per CU  vs  256x256, 1 per CU, deeper DMA pipeline) and, for weight-gradient
+  // shapes (fp32 C, no epilogue, K = all tokens), the K split.  Cost model = rounds of workgroups x K per slice x
+  // measured time per K element + the slab round trip; partial tiles go to `workspace` with plain stores and a second
+  // kernel sums them in a fixed order (no float atomics: deterministic, and several times the atomic byte rate).
+  if (g_tile_mode < 0) {       // MTS_GEMM_TILE=128|256 forces one kernel (A/B testing); default: cost model
+    const char* e = getenv("MTS_GEMM_TILE");
+    g_tile_mode = e ? atoi(e) : 0;
+  }
+  const int tile_mode = g_tile_mode;
+  const unsigned plain = epilogue & ~MTS_EPI_ACCUM;
+  const bool can_split = (c_dtype == MTS_F32 && plain == 0 && has_workspace && N % 4 == 0 && K >= 2048);
+  // (until the transposed LDS reads became inline asm -- gemm_common.h -- the big tiles' TN form was slower than the 128
+  // kernel: one workgroup per CU had nothing to hide the exposed DMA wait behind; now it is the fastest weight-gradient form)
+  const bool can256 = (K % BK == 0) && K >= g_big_min_k && M >= 8 && N >= 8 && tile_mode != 128;
+  const double bw = 3500.0;     // slab MB per us
+  double best = 1e30;
+  int splits = 1;
+  int use256 = 0;               // 0: 128x128 kernel, 1: 256x256, 2: 256x224 (N a multiple of 224: d = 1792 projections)
+  const bool can224 = can256 && (N % 224 == 0) && tile_mode != 256;
+  for (int big = 0; big <= (can256 ? 2 : 0); ++big) {
+    if (big == 2 && !can224) continue;
+    if (tile_mode == 256 && can256 && big != 1) continue;
+    if (tile_mode == 224 && can224 && big != 2) continue;
+    const int tile = big ? 256 : 128;
+    // measured on MI355X (tools/gemm_ksweep.py, gemm_sweep.py): us per K element per round of workgroups, and per-round fixed cost
+    const double slots = big ? 256.0 : 512.0;
+    const double t_k = layout == MTS_TN ? (big == 2 ? 0.0200 : big == 1 ? 0.0218 : 0.0145)          // tools/gemm_tn_sweep.py, gemm_ab.py
+                                        : (big ? 0.0232 * (big == 2 ? 0.875 : 1.0) : 0.0180);
+    const double t_0 = big ? 7.7 : 6.5;
+    const int nt = ceil_div(M, tile) * (big == 2 ? N / 224 : ceil_div(N, tile));
+    for (int sp = 1; sp <= (can_split ? 32 : 1); ++sp) {
+      const int ks = ceil_div(ceil_div(K, sp), BK) * BK;
+      if (ceil_div(K, ks) != sp) continue;
+      if (sp > 1 && (size_t)sp * M * N * sizeof(float) > workspace_bytes) break;
+      if (g_force_splits > 0 && can_split && sp != g_force_splits) continue;
+      const double rounds = ceil((double)nt * sp / slots);
+      const double cost = rounds * (ks * t_k + t_0) + (sp > 1 ? (2.0 * sp + 1.0) * M * N * 4.0 / 1e6 / bw : 0.0);
+      if (cost < best) { best = cost; splits = sp; use256 = big; }
+    }
+  }
+  *use256_out = use256;
+  *splits_out = splits;
+}
+
+extern "C" int mts_gemm_plan(int a_dtype, int c_dtype, int layout, int M, int N, int K, unsigned epilogue, size_t workspace_bytes,
+                             int* tile, int* splits) {
+  MTS_CHECK_ARG(M > 0 && N > 0 && K > 0, "mts_gemm_plan: bad shape M=%d N=%d K=%d", M, N, K);
+  MTS_CHECK_ARG(layout == MTS_NT || layout == MTS_NN || layout == MTS_TN || layout == MTS_TT, "mts_gemm_plan: bad layout %d", layout);
+  MTS_CHECK_ARG(a_dtype == MTS_F32 || a_dtype == MTS_BF16, "mts_gemm_plan: bad a_dtype %d", a_dtype);
+  int use256 = 0, sp = 1;
+  if (a_dtype == MTS_BF16) plan_bf16(c_dtype, layout, M, N, K, epilogue, workspace_bytes > 0, workspace_bytes, &use256, &sp);
+  if (tile) *tile = a_dtype == MTS_F32 ? (g_f32_mfma ? 128 : 64) : use256 == 2 ? 224 : use256 == 1 ? 256 : 128;
+  if (splits) *splits = sp;
+  return MTS_OK;
 }
 
 extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int M, int N, int K, const void* A, int lda,
@@ -776,46 +839,8 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
   MTS_UNSUPPORTED(!(epilogue & MTS_EPI_RESIDUAL) || (ldr % 4 == 0 && ((uintptr_t)residual % 8) == 0), "mts_gemm(bf16): residual alignment");
   MTS_UNSUPPORTED(!aux || (ldaux % 4 == 0 && ((uintptr_t)aux % 8) == 0), "mts_gemm(bf16): aux alignment");
 
-  // Plan: tile size (128x128, 2 workgroups per CU  vs  256x256, 1 per CU, deeper DMA pipeline) and, for weight-gradient
-  // shapes (fp32 C, no epilogue, K = all tokens), the K split.  Cost model = rounds of workgroups x K per slice x
-  // measured time per K element + the slab round trip; partial tiles go to `workspace` with plain stores and a second
-  // kernel sums them in a fixed order (no float atomics: deterministic, and several times the atomic byte rate).
-  if (g_tile_mode < 0) {       // MTS_GEMM_TILE=128|256 forces one kernel (A/B testing); default: cost model
-    const char* e = getenv("MTS_GEMM_TILE");
-    g_tile_mode = e ? atoi(e) : 0;
-  }
-  const int tile_mode = g_tile_mode;
-  const unsigned plain = epilogue & ~MTS_EPI_ACCUM;
-  const bool can_split = (c_dtype == MTS_F32 && plain == 0 && workspace && N % 4 == 0 && K >= 2048);
-  // (until the transposed LDS reads became inline asm -- gemm_common.h -- the big tiles' TN form was slower than the 128
-  // kernel: one workgroup per CU had nothing to hide the exposed DMA wait behind; now it is the fastest weight-gradient form)
-  const bool can256 = (K % BK == 0) && K >= g_big_min_k && M >= 8 && N >= 8 && tile_mode != 128;
-  const double bw = 3500.0;     // slab MB per us
-  double best = 1e30;
-  int splits = 1;
-  int use256 = 0;               // 0: 128x128 kernel, 1: 256x256, 2: 256x224 (N a multiple of 224: d = 1792 projections)
-  const bool can224 = can256 && (N % 224 == 0) && tile_mode != 256;
-  for (int big = 0; big <= (can256 ? 2 : 0); ++big) {
-    if (big == 2 && !can224) continue;
-    if (tile_mode == 256 && can256 && big != 1) continue;
-    if (tile_mode == 224 && can224 && big != 2) continue;
-    const int tile = big ? 256 : 128;
-    // measured on MI355X (tools/gemm_ksweep.py, gemm_sweep.py): us per K element per round of workgroups, and per-round fixed cost
-    const double slots = big ? 256.0 : 512.0;
-    const double t_k = layout == MTS_TN ? (big == 2 ? 0.0200 : big == 1 ? 0.0218 : 0.0145)          // tools/gemm_tn_sweep.py, gemm_ab.py
-                                        : (big ? 0.0232 * (big == 2 ? 0.875 : 1.0) : 0.0180);
-    const double t_0 = big ? 7.7 : 6.5;
-    const int nt = ceil_div(M, tile) * (big == 2 ? N / 224 : ceil_div(N, tile));
-    for (int sp = 1; sp <= (can_split ? 32 : 1); ++sp) {
-      const int ks = ceil_div(ceil_div(K, sp), BK) * BK;
-      if (ceil_div(K, ks) != sp) continue;
-      if (sp > 1 && (size_t)sp * M * N * sizeof(float) > workspace_bytes) break;
-      if (g_force_splits > 0 && can_split && sp != g_force_splits) continue;
-      const double rounds = ceil((double)nt * sp / slots);
-      const double cost = rounds * (ks * t_k + t_0) + (sp > 1 ? (2.0 * sp + 1.0) * M * N * 4.0 / 1e6 / bw : 0.0);
-      if (cost < best) { best = cost; splits = sp; use256 = big; }
-    }
-  }
+  int splits = 1, use256 = 0;
+  plan_bf16(c_dtype, layout, M, N, K, epilogue, workspace != nullptr, workspace_bytes, &use256, &splits);
   g_last_tile = use256 == 2 ? 224 : use256 == 1 ? 256 : 128;
   g_last_splits = splits;
   a.slab = nullptr;

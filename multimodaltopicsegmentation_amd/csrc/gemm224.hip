@@ -667,7 +667,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_224_kernel(const GemmArgs a)
 template <int LAYOUT, typename TC, bool PERSIST, bool MIDBAR>
 static int launch_one_p(const GemmArgs& a, int splits, hipStream_t st) {
   auto k = gemm_bf16_224_kernel<LAYOUT, TC, PERSIST, MIDBAR>;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};   // idempotent process-wide attribute: a race sets it twice
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
     if (e != hipSuccess) { mts_set_error("gemm224: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MTS_ERR_LAUNCH; }

@@ -302,7 +302,7 @@ template <int LAYOUT, typename TC>
 static int launch_one(const GemmArgs& a, int splits, hipStream_t st) {
   constexpr bool PERSIST = sizeof(TC) != 2;
   auto k = gemm_bf16_256_kernel<LAYOUT, TC, PERSIST>;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};   // idempotent process-wide attribute: a race sets it twice
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
     if (e != hipSuccess) { mts_set_error("gemm256: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MTS_ERR_LAUNCH; }

@@ -221,7 +221,7 @@ int mts_lstm_pair_fwd(hipStream_t st, int B, int L, int H, int ndir, const void*
 int mts_lstm_pair_bwd(hipStream_t st, int B, int L, int H, int ndir, const float* w_hh, const int32_t* lengths, const void* out, const void* gates,
                       const float* cells, const void* dout, void* dxproj, void* hprev, void* ws);
 unsigned mts_lstm_pair_take_error();                  // lstm_pair.hip: sticky timeout word (pinned host memory), reading clears
-static int g_lstm_mfma = 1;
+static thread_local int g_lstm_mfma = 1;
 
 // Asynchronous device-side errors, reported without synchronising: today the only source is a CU-pair LSTM launch whose partner
 // poll gave up.  Every mts_lstm_* entry calls this first, so the error surfaces at the next step at the latest.

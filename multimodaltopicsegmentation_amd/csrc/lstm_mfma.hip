@@ -454,7 +454,7 @@ int mts_lstm_mfma_fwd(hipStream_t st, int B, int L, int H, int ndir, const void*
   constexpr int KS = 8;
   const size_t lds = 2 * LM_DOCS * (H + 8) * 2 + (size_t)KS * LM_FWD_LT * KS * 1024 + (size_t)4 * H * sizeof(float);
   auto k = lstm_fwd_mfma_kernel<KS, LM_FWD_RT, LM_FWD_LT>;
-  static bool attr = false;
+  static std::atomic<bool> attr{false};
   if (!attr) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       mts_set_error("lstm_mfma_fwd: cannot reserve %zu bytes of LDS", lds);
@@ -478,7 +478,7 @@ int mts_lstm_mfma_bwd(hipStream_t st, int B, int L, int H, int ndir, const float
   constexpr int KS = 8;
   const size_t lds = 2 * LM_DOCS * (4 * H + 8) * 2 + (size_t)KS * LM_BWD_LT * KS * 1024;
   auto k = lstm_bwd_mfma_kernel<KS, LM_BWD_RT, LM_BWD_LT>;
-  static bool attr = false;
+  static std::atomic<bool> attr{false};
   if (!attr) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       mts_set_error("lstm_mfma_bwd: cannot reserve %zu bytes of LDS", lds);

@@ -323,10 +323,10 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_fwd_pair_kernel(int B, int L,
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
-static int g_pair_mode = -1;   // MTS_LSTM_PAIR=0 disables
+static thread_local int g_pair_mode = -1;   // MTS_LSTM_PAIR=0 disables
 #define LP_MAX_PAIRS 64
-static unsigned g_spin_limit = LP_SPIN_LIMIT;      // mts_set_option("lstm_pair_spin_limit", n): tests force a timeout with n = 0
-static int g_max_pairs = LP_MAX_PAIRS;             // mts_set_option("lstm_pair_max_pairs", n): tests exercise the multi-launch path
+static thread_local unsigned g_spin_limit = LP_SPIN_LIMIT;      // mts_set_option("lstm_pair_spin_limit", n): tests force a timeout with n = 0
+static thread_local int g_max_pairs = LP_MAX_PAIRS;             // mts_set_option("lstm_pair_max_pairs", n): tests exercise the multi-launch path
 static unsigned* g_sticky_host = nullptr;          // pinned, device-visible: non-zero = some pair launch timed out
 static unsigned* g_sticky_dev = nullptr;
 
@@ -376,7 +376,7 @@ int mts_lstm_pair_fwd(hipStream_t st, int B, int L, int H, int ndir, const void*
   if (hipMemsetAsync(xch, 0, pair_xbytes(B, ndir) + 256, st) != hipSuccess) { mts_set_error("lstm_pair: memset failed"); return MTS_ERR_LAUNCH; }
   const size_t lds = (size_t)LP_GROUPS * 2 * LP_DOCS * (H + 8) * 2 + (size_t)4 * (H / 2) * sizeof(float) + (size_t)KS * KS * 1024;
   auto k = lstm_fwd_pair_kernel<KS>;
-  static bool attr = false;
+  static std::atomic<bool> attr{false};
   if (!attr) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       mts_set_error("lstm_pair_fwd: cannot reserve %zu bytes of LDS", lds);
@@ -648,7 +648,7 @@ int mts_lstm_pair_bwd(hipStream_t st, int B, int L, int H, int ndir, const float
                      (bf16_t*)hprev);
   const size_t lds = (size_t)2 * LP_DOCS * ((4 * HH + 8) * 2) + (size_t)KS * (KT / 2) * 1024;
   auto k = lstm_bwd_pair_kernel<KS>;
-  static bool attr = false;
+  static std::atomic<bool> attr{false};
   if (!attr) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       mts_set_error("lstm_pair_bwd: cannot reserve %zu bytes of LDS", lds);
