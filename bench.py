@@ -148,6 +148,39 @@ def infer_latency(args, model, batch, wl, world, rank):
                           'config': {'workload': f'inference: {wl}, {args.docs} document(s) x {args.seq} sentences per call' + (', hipGraph replay' if getattr(args, 'graph', False) and hasattr(model, 'inference_graphs') else '')}}))
 
 
+def other_configs(device, steps=20, warmup=5):
+    """The other BASELINE.json configurations (and the fp32 parity mode an unconfigured drop-in user runs) timed in the same
+    process right after the headline run, so that the driver's record witnesses them too: K steps of fwd + bwd + Adam after W
+    warm-up steps, inputs resident in HBM, one synchronise on either side.  Never part of `value` / `roofline`."""
+    from multimodaltopicsegmentation_amd.rnn_taggers import BiLSTM, BiLSTMLateFusion, BiRnnCrf
+    from multimodaltopicsegmentation_amd.taggers import Transformer_segmenter
+    from multimodaltopicsegmentation_amd.trainer import NativeTrainer
+    runs = [
+        ('configs[2] BiLSTM 2x256 focal, 64x256x1792, bf16', lambda: BiLSTM(2, 1792, 256, num_layers=2, loss_fn='FocalLoss', compute_dtype='bf16', seed=1234), 256, 1792, None, 34.61),
+        ('configs[2] BiLSTM 2x256 + CRF NLL, 64x256x1792, bf16', lambda: BiRnnCrf(2, 1792, 256, num_layers=2, compute_dtype='bf16', seed=1234), 256, 1792, None, 34.62),
+        ('configs[4] per-GPU workload: late fusion 1024+768, 64x512, bf16', lambda: BiLSTMLateFusion(2, [1024, 768], 256, num_layers=2, loss_fn='FocalLoss', compute_dtype='bf16', seed=1234), 512, 1024, 768, 47.19),
+        ('configs[1] in fp32 parity mode (the drop-in classes\' default dtype)', lambda: Transformer_segmenter(2, 1792, 256, num_layers=1, nheads=8, loss_fn='FocalLoss', window_size=30, compute_dtype='fp32', seed=1234), 256, 1792, None, fwd_bwd_mflop_per_sentence(1792, 256, 15, 1)),
+    ]
+    out = {}
+    for label, make, seq, D, D2, mflop in runs:
+        model = make().to(device)
+        trainer = NativeTrainer(model, lr=1e-3, optimizer='Adam')
+        batch = synthetic_batch(64, seq, D, 0, device, D2)
+        for _ in range(warmup):
+            trainer.step(batch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = trainer.step(batch)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        sps = 64 * seq * steps / dt
+        out[label] = {'ms_per_step': 1e3 * dt / steps, 'sentences_per_s': sps, 'steps': steps, 'warmup': warmup,
+                      'model_tflops': sps * mflop / 1e6, 'final_loss': float(loss)}
+        del model, trainer, batch
+    return out
+
+
 def self_launch(n, rehearsal):
     """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start N fresh ranks (one process per GPU) under
     torch.distributed.run on 127.0.0.1 with the same arguments and return their exit code.  Rank 0's JSON line goes straight to the
@@ -189,6 +222,7 @@ def main():
     ap.add_argument('--cpu-docs', type=int, default=32)
     ap.add_argument('--sustained-steps', type=int, default=1000, help='extra timed leg after the K-step region (0 = skip); reported under "extra"')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the 20-step lines of the other BASELINE configurations under "extra"')
     ap.add_argument('--no-kernel-timer', action='store_true')
     ap.add_argument('--ragged', action='store_true', help='ragged lengths U{L/4..L} (value counts valid sentences only)')
     ap.add_argument('--infer', action='store_true', help='inference latency instead of the training step: model(x, lengths) -> scores + boundary lists '
@@ -425,6 +459,8 @@ def main():
                 out['kernels']['band_attn_fwd'] = {**other['band_fwd'], 'algorithmic_GBps': gbs, 'hbm_frac': gbs / HBM_PEAK_GBS}
             if 'band_bwd' in wother:
                 out['kernels']['band_attn_bwd (2 launches)'] = wother['band_bwd']
+        if world == 1 and not single_rank_dp and not args.no_other_configs and cfg_label == 'BASELINE configs[1]':
+            out.setdefault('extra', {})['other_configs'] = other_configs(device)
         if world == 1 and not args.no_cpu_baseline and args.arch == 'transformer':
             out['cpu_baseline'] = cpu_baseline(args, D, ff, heads, window, n_layers)
         print(json.dumps(out))
