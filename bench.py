@@ -181,6 +181,41 @@ def other_configs(device, steps=20, warmup=5):
     return out
 
 
+def h2d_leg(trainer, docs, seq, D, D2, device, steps, warmup, wire='fp32', source='pinned'):
+    """The step with HOST batches in the loop (what a drop-in user who feeds the tagger from a DataLoader gets): three distinct
+    synthetic batches cycled through prefetch.DevicePrefetcher (depth 2: copies on a side stream, two batches ahead).
+    source = 'pinned': the batches sit in pinned host memory (DataLoader(pin_memory=True) / a collater that writes into pinned
+    buffers) -> the leg measures how well the PCIe transfer hides under the step; 'pageable': the prefetcher's producer thread also
+    stages every batch into its pinned ring (one host memcpy of the batch per step).  Never part of `value`."""
+    from multimodaltopicsegmentation_amd.prefetch import DevicePrefetcher
+    host = []
+    for i in range(3):
+        b = synthetic_batch(docs, seq, D, 100 + i, 'cpu', D2)
+        if source == 'pinned':
+            b = {k: (v.pin_memory() if isinstance(v, torch.Tensor) and k in ('src_tokens', 'src_tokens2', 'tgt_tokens') else v) for k, v in b.items()}
+        host.append(b)
+    n_total = warmup + steps
+
+    def cycle():
+        for i in range(n_total):
+            yield host[i % 3]
+    pf = DevicePrefetcher(cycle(), device, depth=2, wire_dtype=wire)
+    t0 = None
+    for i, batch in enumerate(pf):
+        if i == warmup:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        trainer.step(batch)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    per_batch = sum(v.numel() * (2 if (wire == 'bf16' and k != 'tgt_tokens') else 4) for k, v in host[0].items()
+                    if isinstance(v, torch.Tensor) and k in ('src_tokens', 'src_tokens2', 'tgt_tokens'))
+    return {'ms_per_step': 1e3 * dt / steps, 'sentences_per_s': docs * seq * steps / dt, 'steps': steps, 'warmup': warmup,
+            'wire_dtype': wire, 'host_memory': source, 'MB_per_batch': per_batch / 1e6,
+            'pcie_GBps_sustained': per_batch * steps / dt / 1e9,
+            'note': 'host batches -> DevicePrefetcher (side-stream H2D two batches ahead) -> step; NOT the headline value'}
+
+
 def self_launch(n, rehearsal):
     """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start N fresh ranks (one process per GPU) under
     torch.distributed.run on 127.0.0.1 with the same arguments and return their exit code.  Rank 0's JSON line goes straight to the
@@ -221,6 +256,9 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--cpu-docs', type=int, default=32)
     ap.add_argument('--sustained-steps', type=int, default=1000, help='extra timed leg after the K-step region (0 = skip); reported under "extra"')
+    ap.add_argument('--h2d', default=None, choices=['pinned', 'pageable'], help='variant line: host batches through prefetch.DevicePrefetcher '
+                    'in the loop (PCIe-inclusive step); the batches live in pinned or pageable host memory')
+    ap.add_argument('--h2d-wire', default='fp32', choices=['fp32', 'bf16'], help='--h2d: dtype of the embeddings on the wire')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the 20-step lines of the other BASELINE configurations under "extra"')
     ap.add_argument('--no-kernel-timer', action='store_true')
@@ -327,6 +365,17 @@ def main():
 
     if args.infer:
         return infer_latency(args, model, batch, wl, world, rank)
+    if args.h2d:
+        for _ in range(2):
+            trainer.step(batch)                          # allocate workspaces, prime the planner
+        leg = h2d_leg(trainer, args.docs, args.seq, D, D2, device, args.steps, max(args.warmup, 3), args.h2d_wire, args.h2d)
+        if rank == 0:
+            print(json.dumps({'metric': 'sentences/sec (fwd+bwd), host batches in the loop', 'value': world * leg['sentences_per_s'], 'unit': 'sentences/s',
+                              'n_gpus': world, 'steps': args.steps, 'warmup': max(args.warmup, 3), 'ms_per_step': leg['ms_per_step'],
+                              'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+                              'config': {'workload': f'variant (PCIe-inclusive: {args.h2d} host batches, {args.h2d_wire} on the wire) of {cfg_label}: {wl}, '
+                                                     f'{args.docs} docs x {args.seq} sentences per GPU'}, 'h2d': leg}))
+        return
 
     # Warm-up with every GEMM / band-attention launch bracketed by HIP events: finds the dominant kernel symbol and fills the
     # per-kernel table.  An event pair costs a few microseconds of stream time (14 timed launches = ~5 % of this step), so the
@@ -461,6 +510,9 @@ def main():
                 out['kernels']['band_attn_bwd (2 launches)'] = wother['band_bwd']
         if world == 1 and not single_rank_dp and not args.no_other_configs and cfg_label == 'BASELINE configs[1]':
             out.setdefault('extra', {})['other_configs'] = other_configs(device)
+        if world == 1 and not single_rank_dp and not args.no_other_configs and cfg_label == 'BASELINE configs[1]':
+            out['extra']['h2d'] = {f'{src}, {w} on the wire': h2d_leg(trainer, args.docs, args.seq, D, D2, device, 20, 5, w, src)
+                                   for src, w in (('pinned', 'fp32'), ('pageable', 'fp32'), ('pinned', 'bf16'))}
         if world == 1 and not args.no_cpu_baseline and args.arch == 'transformer':
             out['cpu_baseline'] = cpu_baseline(args, D, ff, heads, window, n_layers)
         print(json.dumps(out))

@@ -7,8 +7,9 @@ from . import _lib  # noqa: F401  (raises ImportError when the HIP library is no
 from .encoder_dataset import AudioPortionDataset, AudioPortionDatasetInference  # noqa: F401
 from .datasets import load_dataset_for_inference, load_dataset_from_precomputed, second_input_of  # noqa: F401
 from .lightning_model import TextSegmenter  # noqa: F401
+from .prefetch import DevicePrefetcher  # noqa: F401
 from .rnn_taggers import BiLSTM, BiLSTMLateFusion, BiRnnCrf  # noqa: F401
 from .taggers import RestrictedTransformerEncoderLayer, Transformer_segmenter  # noqa: F401
 
 __all__ = ['TextSegmenter', 'Transformer_segmenter', 'BiLSTM', 'BiLSTMLateFusion', 'BiRnnCrf', 'AudioPortionDataset',
-           'AudioPortionDatasetInference', 'RestrictedTransformerEncoderLayer']
+           'AudioPortionDatasetInference', 'RestrictedTransformerEncoderLayer', 'DevicePrefetcher']

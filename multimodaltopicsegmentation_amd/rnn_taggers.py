@@ -200,6 +200,9 @@ class _RnnTaggerBase(_TaggerBase):
                 return ops.cast_concat(a, b, out)
             x = torch.cat((a, b), dim=1)                               # odd widths (timing features): the padded path below
         x2 = x.reshape(-1, x.shape[-1])
+        if x2.dtype == torch.bfloat16 and self.compute_dtype == torch.bfloat16 and x2.shape[1] % 8 == 0:
+            return x2.contiguous()                                     # already in the act dtype (prefetch.DevicePrefetcher wire_dtype='bf16'):
+                                                                       # the same bits the cast below would produce from the fp32 batch
         if x2.shape[1] % 8:                                           # e.g. 768 + 2 timing features: zero columns up to a multiple of 8
             x2 = torch.nn.functional.pad(x2.to(torch.float32), (0, round_up(x2.shape[1], 8) - x2.shape[1]))
         if self.compute_dtype == torch.float32:

@@ -1,0 +1,65 @@
+"""prefetch.DevicePrefetcher on the GPU: what arrives is what was sent, a training run fed through it equals the same run on
+resident batches bit for bit, and bf16 transport is bit-identical for the recurrent taggers (they round their input to bf16 first)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _host_batches(n, B, L, D, D2=None, pinned=False):
+    g = torch.Generator().manual_seed(9)
+    out = []
+    for _ in range(n):
+        lengths = torch.randint(L // 2, L + 1, (B,), generator=g)
+        lengths[0] = L
+        x = torch.randn(B, L, D, generator=g)
+        y = (torch.rand(B, L, generator=g) < .2).float()
+        x2 = torch.randn(B, L, D2, generator=g) if D2 else None
+        for b, k in enumerate(lengths.tolist()):
+            x[b, k:] = 0
+            y[b, k:] = -1
+            if x2 is not None:
+                x2[b, k:] = 0
+        b = {'id': torch.arange(B), 'src_tokens': x, 'src_lengths': lengths, 'tgt_tokens': y, 'src_tokens2': x2, 'domain': None}
+        if pinned:
+            b = {k: (v.pin_memory() if isinstance(v, torch.Tensor) and v.is_floating_point() else v) for k, v in b.items()}
+        out.append(b)
+    return out
+
+
+@pytest.mark.parametrize('pinned', [False, True])
+def test_batches_arrive_intact_and_in_order(pinned):
+    from multimodaltopicsegmentation_amd import DevicePrefetcher
+    src = _host_batches(9, 4, 64, 256, 128, pinned)
+    pf = DevicePrefetcher(iter(src), DEV, depth=2)
+    for a, b in zip(src, pf):
+        assert b['src_tokens'].device.type == 'cuda' and b['src_lengths'] is a['src_lengths']
+        torch.cuda.current_stream().synchronize()
+        for f in ('src_tokens', 'src_tokens2', 'tgt_tokens'):
+            assert torch.equal(b[f].cpu(), a[f]), f
+    assert pf.bytes_sent == 9 * 4 * 64 * (256 + 128 + 1) * 4
+
+
+@pytest.mark.parametrize('kind', ['transformer', 'bilstm'])
+def test_training_through_the_prefetcher_equals_training_on_resident_batches(kind):
+    from multimodaltopicsegmentation_amd import BiLSTM, DevicePrefetcher, Transformer_segmenter
+    from multimodaltopicsegmentation_amd.trainer import NativeTrainer
+
+    def build():
+        if kind == 'transformer':
+            return Transformer_segmenter(2, 256, 64, num_layers=1, nheads=4, loss_fn='FocalLoss', window_size=8, compute_dtype='bf16',
+                                         max_position_embedding=128, seed=4).to(DEV)
+        return BiLSTM(2, 256, 256, num_layers=1, loss_fn='FocalLoss', compute_dtype='bf16', seed=4).to(DEV)
+    src = _host_batches(6, 8, 64, 256)
+    m1, m2 = build(), build()
+    t1, t2 = NativeTrainer(m1, lr=1e-3), NativeTrainer(m2, lr=1e-3)
+    l1 = [float(t1.step({k: (v.to(DEV) if isinstance(v, torch.Tensor) and v.is_floating_point() else v) for k, v in b.items()})) for b in src]
+    l2 = [float(t2.step(b)) for b in DevicePrefetcher(iter(src), DEV, depth=2)]
+    assert l1 == l2
+    assert torch.equal(m1.flat, m2.flat)
+    if kind == 'bilstm':                      # bf16 on the wire: the recurrent taggers cast their input to bf16 anyway -> same bits
+        m3 = build()
+        t3 = NativeTrainer(m3, lr=1e-3)
+        l3 = [float(t3.step(b)) for b in DevicePrefetcher(iter(src), DEV, depth=2, wire_dtype='bf16')]
+        assert l3 == l1 and torch.equal(m1.flat, m3.flat)
