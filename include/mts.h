@@ -131,7 +131,9 @@ int mts_embed_layernorm_fwd2(void* stream, int dtype, int B, int L, int D1, int 
                              int pos_offset, const float* type0, const float* gamma, const float* beta, float eps,
                              void* y, void* pre, float* mean, float* rstd, const int32_t* row_src, int n_rows);
 /* If head_w != NULL the tagger head is fused in: scores[r,c] = y[r,:].head_w[c,:] + head_b[c] (fp32 [rows,n_out],
- * n_out <= 4), computed on the stored (act dtype) y.  models/CRF.py:579 on top of modeling_longformer.py:1127-1131. */
+ * n_out <= 4), computed on the stored (act dtype) y.  models/CRF.py:579 on top of modeling_longformer.py:1127-1131.
+ * With a fused head and mean/rstd given, y may be NULL: the row is normalised, rounded to the act dtype and fed to the head, but
+ * not written (training step of the last layer: mts_layernorm_bwd recomputes it, see dhead_w there). */
 int mts_layernorm_fwd(void* stream, int dtype, int rows, int D, const void* x, const float* gamma,
                       const float* beta, float eps, void* y, float* mean, float* rstd,
                       const float* head_w, const float* head_b, int n_out, float* scores);
@@ -139,14 +141,28 @@ int mts_layernorm_fwd(void* stream, int dtype, int rows, int D, const void* x, c
  * fp32 [D]) receives colsum(dx) = the bias gradient of the linear layer that produced x.
  * If head_w != NULL the incoming gradient is dy[r,:] (if non-null) + sum_c dlogit[r,c]*head_w[c,:]
  * (the tagger head's data gradient fused in; n_out columns).
+ * If additionally dhead_w != NULL (needs beta, dhead_b, n_out <= 2) the head's PARAMETER gradients are produced in the same pass:
+ * dhead_w[c,:] = sum_r dlogit[r,c] * y[r,:], dhead_b[c] = sum_r dlogit[r,c] (OVERWRITE; models/CRF.py:579's nn.Linear), with
+ * y[r,:] = LN(x[r,:]) recomputed from the saved statistics exactly as the forward rounded it -- the forward of that layer did not
+ * have to store y and no separate mts_head_bwd_params pass reads it.  beta / dhead_w / dhead_b may be NULL together.
  * partial: fp32 workspace of mts_layernorm_bwd_workspace(D) bytes. */
 size_t mts_layernorm_bwd_workspace(int D);
 int mts_layernorm_bwd(void* stream, int dtype, int rows, int D, const void* x, const void* dy,
                       const float* dlogit, const float* head_w, int n_out,
                       const float* gamma, const float* mean, const float* rstd,
-                      void* dx, float* dgamma, float* dbeta, float* dxsum, void* partial);
-/* gradient of the position table: dpos[pos_offset+i,:] += sum_b dpre[b,i,:].  (The token-type row's gradient is
- * sum_{b,i} dpre = the `dxsum` output of the embedding LayerNorm's mts_layernorm_bwd.) */
+                      void* dx, float* dgamma, float* dbeta, float* dxsum, void* partial,
+                      const float* beta, float* dhead_w, float* dhead_b);
+/* Backward of the embedding block in ONE pass (modeling_longformer.py:402-426: LN(x + pos[2+i] + type0)): dh (act dtype [rows, D]) is
+ * the gradient at the LayerNorm's output, pre / mean / rstd what mts_embed_layernorm_fwd saved.  OVERWRITES dgamma, dbeta, dtype0
+ * (= sum over all rows of the pre-LN gradient: the token-type row 0) and rows pos_offset .. pos_offset+L-1 of dpos (= the sum over the
+ * documents of each position; positions no document reaches get 0).  The pre-LN gradient itself is never written to memory.
+ * row0 / lengths / n_rows: packed batches (below), else NULL / NULL / 0.  D <= 2048. */
+size_t mts_embed_layernorm_bwd_workspace(int B, int L, int D);
+int mts_embed_layernorm_bwd(void* stream, int dtype, int B, int L, int D, const void* pre, const void* dh, const float* gamma,
+                            const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dtype0, float* dpos,
+                            int pos_offset, const int32_t* row0, const int32_t* lengths, int n_rows, void* workspace, size_t workspace_bytes);
+/* gradient of the position table from a STORED pre-LN gradient: dpos[pos_offset+i,:] += sum_b dpre[b,i,:].  (The token-type row's
+ * gradient is sum_{b,i} dpre = the `dxsum` output of the embedding LayerNorm's mts_layernorm_bwd.)  Kept for D > 2048. */
 int mts_embed_bwd(void* stream, int dtype, int B, int L, int D, const void* dpre, float* dpos, int pos_offset,
                   const int32_t* row0, const int32_t* lengths);
 

@@ -43,7 +43,9 @@ SIGNATURES = {
     'mts_embed_layernorm_fwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i]),
     'mts_layernorm_fwd': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'mts_layernorm_bwd_workspace': (_sz, [_i]),
-    'mts_layernorm_bwd': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'mts_layernorm_bwd': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'mts_embed_layernorm_bwd_workspace': (_sz, [_i, _i, _i]),
+    'mts_embed_layernorm_bwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz]),
     'mts_embed_bwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     'mts_dropout_fwd': (_i, [_vp, _i, _sz, _vp, _vp, _vp, _vp, _f, C.c_uint64]),
     'mts_dropout_bwd': (_i, [_vp, _i, _sz, _vp, _vp, _vp, _f]),

@@ -136,10 +136,12 @@ __global__ __launch_bounds__(64 * ROW_WAVES) void ln_fwd_kernel(
       }
     }
   }
+  if (y) {          // NULL: the caller only wants the fused head's scores and the statistics (the backward recomputes y, see ln_bwd_kernel NHG)
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int e = 4 * (lane + 64 * i);
-    if (FULL || e < D) store4<T>(y + (size_t)row * D + e, x[i]);
+    for (int i = 0; i < NV; ++i) {
+      const int e = 4 * (lane + 64 * i);
+      if (FULL || e < D) store4<T>(y + (size_t)row * D + e, x[i]);
+    }
   }
   if (lane == 0 && mean_out) { mean_out[row] = mean; rstd_out[row] = rstd; }
   if (head_w) {
@@ -207,38 +209,69 @@ __global__ __launch_bounds__(256) void head_bwd_data_kernel(const float* __restr
 // FULL (D == NV * 256, e.g. 1792 = 7 x 256): every lane owns a valid column in every slot, so the per-slot bounds checks go away --
 // with them the divergent branches around the loads and stores, behind which the compiler waits for ALL outstanding memory
 // operations (the next row's prefetch, the previous slot's store acknowledgement) before every slot.
-template <typename T, int NV, bool WIDE, bool FULL = false>
+// NHG > 0 (head_w given, dy == NULL: the LAST layer of a tagger, whose only incoming gradient is the fused head's): the head's
+// PARAMETER gradients come out of this pass too, and the forward of that layer need not store its output y = xhat * gamma + beta.
+// With dv[r,e] = sum_c dl[r,c] w[c,e] everything the pass owes is a function of  S_c[e] = sum_r dl[r,c] xhat[r,e]  and the
+// scalars  T_c = sum_r dl[r,c]:
+//     dgamma[e] = sum_c w[c,e] S_c[e]      dbeta[e] = sum_c w[c,e] T_c      dw[c,e] = gamma[e] S_c[e] + beta[e] T_c      db[c] = T_c
+// so the wave accumulates S_c (NHG x NV x 4 registers instead of dgamma + dbeta) and ln_head_final_kernel forms the four outputs
+// (slab slots 0 .. NHG-1: S_c, slot NHG: colsum(dx), slot NHG+1: T_c in its first NHG entries).  dw is taken on the UNROUNDED y
+// (the forward fed the head the act-dtype rounding of it): the gradient of the function the reference computes.
+// EMB: backward of the EMBEDDING LayerNorm (modeling_longformer.py:402-426).  Its dx is only ever summed: over every row into the
+// token-type row and over the documents of each position i into the position table.  A wave therefore walks ONE position through a
+// chunk of documents (task = chunk * L + i; rows b*L + i, or row0[b] + i of a packed batch), keeps the running sum in registers and
+// writes it once per task to dpos_part[chunk][i][:] (fp32; pos_sum_kernel adds the chunks and forms the token-type row) -- dx
+// itself is never stored and never re-read (was: 58.7 MB written + read back by embed_bwd_kernel at the BASELINE shape).
+// Slab slots: 0 dgamma, 1 dbeta.
+struct EmbArgs { int B, L, Bc, nchunks; const int32_t* row0; const int32_t* lengths; float* dpos_part; };
+
+template <typename T, int NV, bool WIDE, bool FULL = false, int NHG = 0, bool EMB = false>
 __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
-    const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ dlogit, const float* __restrict__ head_w, int n_out,
+    const T* __restrict__ x, const T* __restrict__ dy_, const float* __restrict__ dlogit, const float* __restrict__ head_w, int n_out,
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd, int rows, int D,
-    T* __restrict__ dx, float* __restrict__ partial) {
-  __shared__ float red[ROW_WAVES][3][64 * 4];   // one vector slot at a time is combined through LDS
+    T* __restrict__ dx, float* __restrict__ partial, const EmbArgs ea) {
+  static_assert(!(EMB && (WIDE || NHG > 0)), "the embedding form has no head and D <= 2048");
+  constexpr bool HG = NHG > 0;
+  constexpr int NR = HG ? NHG + 1 : EMB ? 2 : 3;       // full-width slots per workgroup slab
+  constexpr int NS = HG ? NHG + 2 : NR;                // + the short slot of the T_c scalars
+  constexpr int NA = HG ? NHG : 2;                     // per-column accumulator sets besides the dx sum: S_c, or dgamma + dbeta
+  const T* __restrict__ dy = HG ? nullptr : dy_;
+  __shared__ float red[ROW_WAVES][NR][64 * 4];         // one vector slot at a time is combined through LDS
   // gamma and the head weights of this workgroup's columns live in LDS for the whole kernel: row-invariant, too many for the
   // register file, and as global loads inside the row loop every one of them made the compiler wait for the next row's prefetch
   __shared__ __attribute__((aligned(16))) float gam_s[NV * 256];
-  __shared__ __attribute__((aligned(16))) float hw_s[4][NV * 256];
+  __shared__ __attribute__((aligned(16))) float hw_s[EMB ? 1 : 4][EMB ? 4 : NV * 256];
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row / task bookkeeping lives in scalar registers
   const int col0 = WIDE ? (int)blockIdx.y * (NV * 256) : 0;
   for (int idx = threadIdx.x; idx < NV * 256; idx += 64 * ROW_WAVES) {
     const int e = col0 + idx;
     gam_s[idx] = (e < D) ? gamma[e] : 0.f;
-    if (head_w)
-      for (int c = 0; c < n_out; ++c) hw_s[c][idx] = (e < D) ? head_w[(size_t)c * D + e] : 0.f;
+    if constexpr (!EMB) {
+      if (head_w)
+        for (int c = 0; c < n_out; ++c) hw_s[c][idx] = (e < D) ? head_w[(size_t)c * D + e] : 0.f;
+    }
   }
   __syncthreads();
-  float dg[NV][4], db[NV][4], dxs[NV][4];
+  float acc[NA][NV][4];          // HG: S_c;  else [0] = dgamma, [1] = dbeta
+  float dxs[NV][4];              // colsum(dx); EMB: the running sum of the current task (one position, a chunk of documents)
+  float tsum[HG ? NHG : 1];
 #pragma unroll
   for (int i = 0; i < NV; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dg[i][j] = db[i][j] = dxs[i][j] = 0.f;
+    for (int j = 0; j < 4; ++j) {
+      dxs[i][j] = 0.f;
+#pragma unroll
+      for (int c = 0; c < NA; ++c) acc[c][i][j] = 0.f;
+    }
+#pragma unroll
+  for (int c = 0; c < (HG ? NHG : 1); ++c) tsum[c] = 0.f;
 
   const float invD = 1.0f / (float)D;
   // the next row's x / dy are fetched (raw, storage precision) before the current row is reduced, so a wave always has
   // a full row of loads in flight behind its arithmetic and its stores
   const int stride = gridDim.x * ROW_WAVES;
-  int row = blockIdx.x * ROW_WAVES + wave;
-  Pack<T, 4> px[NV], pd[NV];
+  Pack<T, 4> px[NV], pd[HG ? 1 : NV];
   // the row's statistics and head gradients travel with the prefetch (unconditional loads from a pointer that is always valid),
   // so that the wait for them at the top of the next iteration is a counted one that leaves this row's stores in flight
   float mu_n = 0.f, rs_n = 0.f, dl_n[4] = {0.f, 0.f, 0.f, 0.f};
@@ -247,19 +280,51 @@ __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
   auto fetch = [&](int r) {
     mu_n = mean[r];
     rs_n = rstd[r];
+    if constexpr (!EMB) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) dl_n[c] = dlp[(size_t)r * dl_mul + min(c, dl_max)];
+      for (int c = 0; c < 4; ++c) dl_n[c] = dlp[(size_t)r * dl_mul + min(c, dl_max)];
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int e = col0 + 4 * (lane + 64 * i);
       if (FULL || e < D) {
         px[i].load(x + (size_t)r * D + e);
-        if (dy) pd[i].load(dy + (size_t)r * D + e);
+        if constexpr (!HG) { if (dy) pd[i].load(dy + (size_t)r * D + e); }
       }
     }
   };
-  if (row < rows) fetch(row);
-  for (; row < rows; row += stride) {
+  // ---- which rows this wave visits ---------------------------------------------------------------------------------------
+  //   plain: rows w, w + stride, ...          EMB: tasks w, w + stride, ...; inside a task the documents of its chunk, one position
+  int task = blockIdx.x * ROW_WAVES + wave;              // EMB: task id; plain: the row itself
+  int ti = 0, tb = 0, tbend = 0;
+  const int ntasks = EMB ? ea.L * ea.nchunks : 0;
+  auto row_at = [&](int b, int i) { return ea.row0 ? ea.row0[b] + i : b * ea.L + i; };
+  auto valid = [&](int b, int i) { return !ea.row0 || i < ea.lengths[b]; };
+  auto open_task = [&](int t) {                           // -> false when no document of the chunk reaches position ti
+    ti = t % ea.L;
+    tb = (t / ea.L) * ea.Bc;
+    tbend = min(ea.B, tb + ea.Bc);
+    while (tb < tbend && !valid(tb, ti)) ++tb;
+    return tb < tbend;
+  };
+  auto write_task = [&](int t, const float (&v)[NV][4]) {
+    float* o = ea.dpos_part + (size_t)t * D;             // [chunk][i][D] = [t][D]
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = 4 * (lane + 64 * i);
+      if (FULL || e < D) store4<float>(o + e, v[i]);
+    }
+  };
+  auto skip_empty_tasks = [&]() {                         // leaves `task` on a task with at least one row, or >= ntasks
+    if constexpr (EMB) {
+      while (task < ntasks && !open_task(task)) task += stride;    // (packed batches: the host zeroed dpos_part, an empty task writes nothing)
+    }
+  };
+  int row;
+  if constexpr (EMB) { skip_empty_tasks(); row = task < ntasks ? row_at(tb, ti) : -1; }
+  else row = task < rows ? task : -1;
+  if (row >= 0) fetch(row);
+  while (row >= 0) {
     const float mu = mu_n, rs = rs_n;
     float xh[NV][4], gy[NV][4];
     float s1 = 0.f, s2 = 0.f;
@@ -269,10 +334,29 @@ __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
       const int e = col0 + 4 * (lane + 64 * i);
       if (FULL || e < D) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { xh[i][j] = px[i].get(j); gy[i][j] = dy ? pd[i].get(j) : 0.f; }
+        for (int j = 0; j < 4; ++j) {
+          xh[i][j] = px[i].get(j);
+          if constexpr (HG) gy[i][j] = 0.f;
+          else gy[i][j] = dy ? pd[i].get(j) : 0.f;
+        }
       }
     }
-    if (row + stride < rows) fetch(row + stride);
+    // next row (and, EMB, whether the current one closes its task)
+    int nrow = -1, done_task = -1;
+    if constexpr (EMB) {
+      int b = tb + 1;
+      while (b < tbend && !valid(b, ti)) ++b;
+      if (b < tbend) { tb = b; nrow = row_at(tb, ti); }
+      else {
+        done_task = task;
+        task += stride;
+        skip_empty_tasks();
+        if (task < ntasks) nrow = row_at(tb, ti);
+      }
+    } else {
+      if (row + stride < rows) nrow = row + stride;
+    }
+    if (nrow >= 0) fetch(nrow);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int e = col0 + 4 * (lane + 64 * i);
@@ -281,28 +365,38 @@ __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
         const float4 g4v = *reinterpret_cast<const float4*>(gam_s + (e - col0));
         const float gv[4] = {g4v.x, g4v.y, g4v.z, g4v.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dv[j] = gy[i][j];
-        if (head_w) {
-          for (int c = 0; c < n_out; ++c) {
-            const float4 w4v = *reinterpret_cast<const float4*>(hw_s[c] + (e - col0));
-            const float wv[4] = {w4v.x, w4v.y, w4v.z, w4v.w};
+        for (int j = 0; j < 4; ++j) { dv[j] = gy[i][j]; xh[i][j] = (xh[i][j] - mu) * rs; }
+        if constexpr (!EMB) {
+          if (head_w) {
+            for (int c = 0; c < n_out; ++c) {
+              const float4 w4v = *reinterpret_cast<const float4*>(hw_s[c] + (e - col0));
+              const float wv[4] = {w4v.x, w4v.y, w4v.z, w4v.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dv[j] += dl[c] * wv[j];
+              for (int j = 0; j < 4; ++j) dv[j] += dl[c] * wv[j];
+            }
           }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          xh[i][j] = (xh[i][j] - mu) * rs;
           gy[i][j] = dv[j] * gv[j];
           s1 += gy[i][j];
           s2 += gy[i][j] * xh[i][j];
-          dg[i][j] += dv[j] * xh[i][j];
-          db[i][j] += dv[j];
+          if constexpr (HG) {
+#pragma unroll
+            for (int c = 0; c < NHG; ++c) acc[c][i][j] += dl[c] * xh[i][j];
+          } else {
+            acc[0][i][j] += dv[j] * xh[i][j];
+            acc[1][i][j] += dv[j];
+          }
         }
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { xh[i][j] = 0.f; gy[i][j] = 0.f; }
       }
+    }
+    if constexpr (HG) {
+#pragma unroll
+      for (int c = 0; c < NHG; ++c) tsum[c] += dl[c];
     }
     if constexpr (WIDE) {
       for (int oc = 0; oc < (int)gridDim.y; ++oc) {
@@ -339,26 +433,34 @@ __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           o[j] = rs * (gy[i][j] - s1 - xh[i][j] * s2);
-          if constexpr (sizeof(T) == 2) o[j] = to_f32(from_f32<T>(o[j]));   // sum what is stored
+          if constexpr (!EMB && sizeof(T) == 2) o[j] = to_f32(from_f32<T>(o[j]));   // sum what is stored (EMB: nothing is stored, fp32 throughout)
           dxs[i][j] += o[j];
         }
-        store4<T>(dx + (size_t)row * D + e, o);
+        if constexpr (!EMB) store4<T>(dx + (size_t)row * D + e, o);
       }
     }
+    if constexpr (EMB) {
+      if (done_task >= 0) {
+        write_task(done_task, dxs);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) dxs[i][0] = dxs[i][1] = dxs[i][2] = dxs[i][3] = 0.f;
+      }
+    }
+    row = nrow;
   }
   // combine the ROW_WAVES waves of this workgroup, one vector slot (256 columns) at a time
-  float* slab = partial + (size_t)blockIdx.x * 3 * D;
+  float* slab = partial + (size_t)blockIdx.x * NS * D;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      red[wave][0][lane * 4 + j] = dg[i][j];
-      red[wave][1][lane * 4 + j] = db[i][j];
-      red[wave][2][lane * 4 + j] = dxs[i][j];
+#pragma unroll
+      for (int c = 0; c < NA; ++c) red[wave][c][lane * 4 + j] = acc[c][i][j];
+      if constexpr (!EMB) red[wave][NA][lane * 4 + j] = dxs[i][j];
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < 3 * 256; t += 64 * ROW_WAVES) {
+    for (int t = threadIdx.x; t < NR * 256; t += 64 * ROW_WAVES) {
       const int slot = t / 256, col = t % 256;
       const int e = col0 + 256 * i + col;
       if (FULL || e < D) {
@@ -368,6 +470,110 @@ __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
         slab[(size_t)slot * D + e] = s;
       }
     }
+  }
+  if constexpr (HG) {
+    __syncthreads();
+    if (lane == 0)
+      for (int c = 0; c < NHG; ++c) red[wave][c][0] = tsum[c];
+    __syncthreads();
+    if (threadIdx.x < NHG && blockIdx.y == 0) {
+      float s = 0.f;
+      for (int w = 0; w < ROW_WAVES; ++w) s += red[w][threadIdx.x][0];
+      slab[(size_t)(NHG + 1) * D + threadIdx.x] = s;
+    }
+  }
+}
+
+// Final step of the NHG form of ln_bwd_kernel: reduces the slabs (S_c, colsum(dx), T_c) over the workgroups in a fixed order and forms
+// dgamma, dbeta, dxsum, dw[c], db[c] (see the kernel's header).  Workgroup = 32 columns x 32 block-groups, as slab_reduce_kernel.
+template <int NHG>
+__global__ __launch_bounds__(256) void ln_head_final_kernel(const float* __restrict__ partial, int nblocks, int D, const float* __restrict__ head_w,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dxsum,
+                                                            float* __restrict__ dhead_w, float* __restrict__ dhead_b) {
+  constexpr int NS = NHG + 2;
+  __shared__ float4 red[NHG + 1][32][8];
+  __shared__ float tred[NHG][256];
+  const int c4 = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  const int e = blockIdx.x * 32 + 4 * c4;
+  const size_t bs = (size_t)NS * D;
+  float4 s[NHG + 1];
+#pragma unroll
+  for (int k = 0; k <= NHG; ++k) s[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e < D) {
+    for (int b = grp; b < nblocks; b += 32) {
+#pragma unroll
+      for (int k = 0; k <= NHG; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)b * bs + (size_t)k * D + e);
+        s[k].x += v.x; s[k].y += v.y; s[k].z += v.z; s[k].w += v.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k <= NHG; ++k) red[k][grp][c4] = s[k];
+  // T_c: every workgroup sums the nblocks scalars itself (a few hundred values), in the same fixed order
+#pragma unroll
+  for (int c = 0; c < NHG; ++c) {
+    float t = 0.f;
+    for (int b = threadIdx.x; b < nblocks; b += 256) t += partial[(size_t)b * bs + (size_t)(NHG + 1) * D + c];
+    tred[c][threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (grp == 0 && e < D) {
+    float T[NHG];
+#pragma unroll
+    for (int c = 0; c < NHG; ++c) { float t = 0.f; for (int k = 0; k < 256; ++k) t += tred[c][k]; T[c] = t; }
+    float S[NHG + 1][4];
+#pragma unroll
+    for (int k = 0; k <= NHG; ++k) {
+      float4 t = red[k][0][c4];
+      for (int gi = 1; gi < 32; ++gi) { const float4 v = red[k][gi][c4]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+      S[k][0] = t.x; S[k][1] = t.y; S[k][2] = t.z; S[k][3] = t.w;
+    }
+    float gv[4], bv[4], dg[4] = {0.f, 0.f, 0.f, 0.f}, dbt[4] = {0.f, 0.f, 0.f, 0.f};
+    load4<float>(gamma + e, gv);
+    load4<float>(beta + e, bv);
+#pragma unroll
+    for (int c = 0; c < NHG; ++c) {
+      float wv[4], dwv[4];
+      load4<float>(head_w + (size_t)c * D + e, wv);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { dg[j] += wv[j] * S[c][j]; dbt[j] += wv[j] * T[c]; dwv[j] = gv[j] * S[c][j] + bv[j] * T[c]; }
+      store4<float>(dhead_w + (size_t)c * D + e, dwv);
+    }
+    store4<float>(dgamma + e, dg);
+    store4<float>(dbeta + e, dbt);
+    if (dxsum) store4<float>(dxsum + e, S[NHG]);
+    if (blockIdx.x == 0 && c4 == 0)
+      for (int c = 0; c < NHG; ++c) dhead_b[c] = T[c];
+  }
+}
+
+// Final step of the EMB form: dpos[i][e] = sum_chunks part[chunk][i][e] for every position, and dtype0[e] = sum_i dpos[i][e] (the
+// token-type row = the sum of the pre-LN gradient over all rows), both in a fixed order.  Workgroup = 32 columns x 32 row-groups.
+__global__ __launch_bounds__(256) void pos_sum_kernel(const float* __restrict__ part, int nchunks, int L, int D, float* __restrict__ dpos_rows,
+                                                      float* __restrict__ dtype0) {
+  __shared__ float4 red[32][8];
+  const int c4 = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  const int e = blockIdx.x * 32 + 4 * c4;
+  float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e < D) {
+    for (int i = grp; i < L; i += 32) {
+      float4 s = *reinterpret_cast<const float4*>(part + (size_t)i * D + e);
+      for (int c = 1; c < nchunks; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(part + ((size_t)c * L + i) * D + e);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      if (nchunks > 1 || part != dpos_rows) *reinterpret_cast<float4*>(dpos_rows + (size_t)i * D + e) = s;
+      tot.x += s.x; tot.y += s.y; tot.z += s.z; tot.w += s.w;
+    }
+  }
+  red[grp][c4] = tot;
+  __syncthreads();
+  if (grp == 0 && e < D) {
+    float4 t = red[0][c4];
+    for (int gi = 1; gi < 32; ++gi) { const float4 v = red[gi][c4]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    *reinterpret_cast<float4*>(dtype0 + e) = t;
   }
 }
 
@@ -459,16 +665,15 @@ __global__ __launch_bounds__(64 * ROW_WAVES) void head_bwd_params_kernel(const T
 // lane streams 16-byte loads with up to 8 in flight, then the 32 groups are combined through LDS in a fixed order
 // (bitwise reproducible).  D must be a multiple of 4 (the row kernels above require it already).
 #define SR_COLS 32
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ partial, int nblocks, int nslots, int D,
-                                                          float* out0, float* out1, float* out2, float* out3, float* out4, int len4) {
+struct SlabOuts { float* o[6]; int short_slot, short_len; };   // one output row per slot (NULL: skipped); slot `short_slot` has only short_len entries
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ partial, int nblocks, int nslots, int D, const SlabOuts so) {
   __shared__ float4 red[32][8];
   const int c4 = threadIdx.x & 7, grp = threadIdx.x >> 3;
   const int e = blockIdx.x * SR_COLS + 4 * c4;
   const int slot = blockIdx.y;
-  float* outs[5] = {out0, out1, out2, out3, out4};
-  float* o = outs[slot];
+  float* o = so.o[slot];
   if (!o) return;
-  const int len = (slot == 4) ? len4 : D;
+  const int len = (slot == so.short_slot) ? so.short_len : D;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e < len) {
     const float* p = partial + (size_t)slot * D + e;
@@ -499,8 +704,8 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 
 // used by band_attn.hip for the fused q/k/v bias gradient
 int mts_slab_reduce_rows(hipStream_t st, const float* partial, int nblocks, int D, float* out) {
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(D, SR_COLS), 1), dim3(256), 0, st, partial, nblocks, 1, D, out, (float*)nullptr,
-                     (float*)nullptr, (float*)nullptr, (float*)nullptr, 0);
+  SlabOuts so = {{out, nullptr, nullptr, nullptr, nullptr, nullptr}, -1, 0};
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(D, SR_COLS), 1), dim3(256), 0, st, partial, nblocks, 1, D, so);
   MTS_LAUNCH_CHECK("slab_reduce");
   return MTS_OK;
 }
@@ -636,7 +841,7 @@ extern "C" int mts_embed_layernorm_fwd2(void* stream, int dtype, int B, int L, i
 
 extern "C" int mts_layernorm_fwd(void* stream, int dtype, int rows, int D, const void* x, const float* gamma, const float* beta, float eps,
                                  void* y, float* mean, float* rstd, const float* head_w, const float* head_b, int n_out, float* scores) {
-  MTS_CHECK_ARG(rows > 0 && D > 0 && x && gamma && beta && y, "mts_layernorm_fwd: bad arguments");
+  MTS_CHECK_ARG(rows > 0 && D > 0 && x && gamma && beta && (y || (head_w && mean && rstd)), "mts_layernorm_fwd: bad arguments (y may be NULL only with a fused head and saved statistics)");
   MTS_CHECK_ARG(!head_w || (head_b && scores && n_out >= 1 && n_out <= 4), "mts_layernorm_fwd: fused head needs head_b, scores, n_out<=4");
   if (dtype == MTS_F32)
     return ln_fwd_launch<float, false>((hipStream_t)stream, x, nullptr, 0, 1, nullptr, gamma, beta, eps, rows, D, y, nullptr, mean, rstd,
@@ -648,46 +853,122 @@ extern "C" int mts_layernorm_fwd(void* stream, int dtype, int rows, int D, const
   return MTS_ERR_INVALID;
 }
 
-extern "C" size_t mts_layernorm_bwd_workspace(int D) { return (size_t)BWD_MAX_BLOCKS * 5 * (size_t)D * sizeof(float); }
+extern "C" size_t mts_layernorm_bwd_workspace(int D) { return (size_t)BWD_MAX_BLOCKS * 6 * (size_t)D * sizeof(float); }
 
 template <typename T>
 static int ln_bwd_launch(hipStream_t st, int rows, int D, const void* x, const void* dy, const float* dlogit, const float* head_w, int n_out,
-                         const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, float* dxsum,
-                         void* partial) {
+                         const float* gamma, const float* beta, const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+                         float* dxsum, float* dhead_w, float* dhead_b, void* partial) {
   const int nv = pick_nv(D);
   MTS_UNSUPPORTED(nv > 0 && D % 4 == 0, "layernorm_bwd: D=%d must be a multiple of 4 and <= 4096", D);
   const int blocks = std::min(BWD_MAX_BLOCKS, ceil_div(rows, ROW_WAVES));
+  const int nhg = dhead_w ? n_out : 0;
+  const EmbArgs ea = {0, 0, 0, 0, nullptr, nullptr, nullptr};
+  auto go = [&](auto k, dim3 grid) {
+    hipLaunchKernelGGL(k, grid, dim3(64 * ROW_WAVES), 0, st, (const T*)x, (const T*)dy, dlogit, head_w, n_out, gamma, mean, rstd, rows, D,
+                       (T*)dx, (float*)partial, ea);
+  };
   if (nv <= 8) {
     dispatch_nv8(nv, [&](auto nvc) {
       constexpr int NV = decltype(nvc)::value;
-      if (D == NV * 256)
-        hipLaunchKernelGGL((ln_bwd_kernel<T, NV, false, true>), dim3(blocks), dim3(64 * ROW_WAVES), 0, st, (const T*)x, (const T*)dy, dlogit, head_w,
-                           n_out, gamma, mean, rstd, rows, D, (T*)dx, (float*)partial);
-      else
-        hipLaunchKernelGGL((ln_bwd_kernel<T, NV, false>), dim3(blocks), dim3(64 * ROW_WAVES), 0, st, (const T*)x, (const T*)dy, dlogit, head_w, n_out,
-                           gamma, mean, rstd, rows, D, (T*)dx, (float*)partial);
+      if (D == NV * 256) {
+        if (nhg == 1) go(ln_bwd_kernel<T, NV, false, true, 1>, dim3(blocks));
+        else if (nhg == 2) go(ln_bwd_kernel<T, NV, false, true, 2>, dim3(blocks));
+        else go(ln_bwd_kernel<T, NV, false, true>, dim3(blocks));
+      } else {
+        if (nhg == 1) go(ln_bwd_kernel<T, NV, false, false, 1>, dim3(blocks));
+        else if (nhg == 2) go(ln_bwd_kernel<T, NV, false, false, 2>, dim3(blocks));
+        else go(ln_bwd_kernel<T, NV, false>, dim3(blocks));
+      }
     });
   } else {   // 2048 < D <= 4096 (e.g. 768 + 1536 = 2304): two column chunks of 2048
-    hipLaunchKernelGGL((ln_bwd_kernel<T, 8, true>), dim3(blocks, ceil_div(D, 2048)), dim3(64 * ROW_WAVES), 0, st, (const T*)x, (const T*)dy, dlogit,
-                       head_w, n_out, gamma, mean, rstd, rows, D, (T*)dx, (float*)partial);
+    if (nhg == 1) go(ln_bwd_kernel<T, 8, true, false, 1>, dim3(blocks, ceil_div(D, 2048)));
+    else if (nhg == 2) go(ln_bwd_kernel<T, 8, true, false, 2>, dim3(blocks, ceil_div(D, 2048)));
+    else go(ln_bwd_kernel<T, 8, true>, dim3(blocks, ceil_div(D, 2048)));
   }
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(D, SR_COLS), 3), dim3(256), 0, st, (const float*)partial, blocks, 3, D, dgamma, dbeta,
-                     dxsum, (float*)nullptr, (float*)nullptr, 0);
+  if (nhg == 1)
+    hipLaunchKernelGGL(ln_head_final_kernel<1>, dim3(ceil_div(D, 32)), dim3(256), 0, st, (const float*)partial, blocks, D, head_w, gamma, beta, dgamma,
+                       dbeta, dxsum, dhead_w, dhead_b);
+  else if (nhg == 2)
+    hipLaunchKernelGGL(ln_head_final_kernel<2>, dim3(ceil_div(D, 32)), dim3(256), 0, st, (const float*)partial, blocks, D, head_w, gamma, beta, dgamma,
+                       dbeta, dxsum, dhead_w, dhead_b);
+  else {
+    SlabOuts so = {{dgamma, dbeta, dxsum, nullptr, nullptr, nullptr}, -1, 0};
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(D, SR_COLS), 3), dim3(256), 0, st, (const float*)partial, blocks, 3, D, so);
+  }
   MTS_LAUNCH_CHECK("layernorm_bwd");
   return MTS_OK;
 }
 
 extern "C" int mts_layernorm_bwd(void* stream, int dtype, int rows, int D, const void* x, const void* dy, const float* dlogit,
                                  const float* head_w, int n_out, const float* gamma, const float* mean, const float* rstd, void* dx,
-                                 float* dgamma, float* dbeta, float* dxsum, void* partial) {
+                                 float* dgamma, float* dbeta, float* dxsum, void* partial, const float* beta, float* dhead_w, float* dhead_b) {
   MTS_CHECK_ARG(rows > 0 && D > 0 && x && gamma && mean && rstd && dx && partial, "mts_layernorm_bwd: bad arguments");
   MTS_CHECK_ARG(dy || head_w, "mts_layernorm_bwd: needs dy and/or a fused head gradient");
   MTS_CHECK_ARG(!head_w || (dlogit && n_out >= 1 && n_out <= 4), "mts_layernorm_bwd: fused head needs dlogit, n_out<=4");
+  MTS_CHECK_ARG(!dhead_w || (head_w && beta && dhead_b && n_out <= 2 && !dy),
+                "mts_layernorm_bwd: head parameter gradients need head_w, beta, dhead_b, n_out <= 2 and dy == NULL (the last layer)");
   if (dtype == MTS_F32)
-    return ln_bwd_launch<float>((hipStream_t)stream, rows, D, x, dy, dlogit, head_w, n_out, gamma, mean, rstd, dx, dgamma, dbeta, dxsum, partial);
+    return ln_bwd_launch<float>((hipStream_t)stream, rows, D, x, dy, dlogit, head_w, n_out, gamma, beta, mean, rstd, dx, dgamma, dbeta, dxsum, dhead_w, dhead_b, partial);
   if (dtype == MTS_BF16)
-    return ln_bwd_launch<bf16_t>((hipStream_t)stream, rows, D, x, dy, dlogit, head_w, n_out, gamma, mean, rstd, dx, dgamma, dbeta, dxsum, partial);
+    return ln_bwd_launch<bf16_t>((hipStream_t)stream, rows, D, x, dy, dlogit, head_w, n_out, gamma, beta, mean, rstd, dx, dgamma, dbeta, dxsum, dhead_w, dhead_b, partial);
   mts_set_error("mts_layernorm_bwd: bad dtype %d", dtype);
+  return MTS_ERR_INVALID;
+}
+
+// ---- backward of the embedding block in one pass: LayerNorm backward + position / token-type gradient ------------------------------
+static inline int emb_chunks(int B, int L) { return std::max(1, std::min(B, ceil_div(4 * BWD_MAX_BLOCKS, L))); }
+extern "C" size_t mts_embed_layernorm_bwd_workspace(int B, int L, int D) {
+  return ((size_t)BWD_MAX_BLOCKS * 2 + (size_t)emb_chunks(B, L) * L) * (size_t)D * sizeof(float);
+}
+
+template <typename T>
+static int emb_bwd_launch(hipStream_t st, int B, int L, int D, const void* pre, const void* dh, const float* gamma, const float* mean, const float* rstd,
+                          float* dgamma, float* dbeta, float* dtype0, float* dpos, int pos_offset, const int32_t* row0, const int32_t* lengths,
+                          int n_rows, float* ws) {
+  const int nv = pick_nv(D);
+  MTS_UNSUPPORTED(nv > 0 && nv <= 8 && D % 4 == 0, "embed_layernorm_bwd: D=%d must be a multiple of 4 and <= 2048", D);
+  const int C = emb_chunks(B, L), Bc = ceil_div(B, C);
+  const int nchunks = ceil_div(B, Bc);
+  const int ntasks = L * nchunks;
+  const int blocks = std::min(BWD_MAX_BLOCKS, ceil_div(ntasks, ROW_WAVES));
+  float* slabs = ws;
+  float* part = ws + (size_t)BWD_MAX_BLOCKS * 2 * D;
+  float* out_rows = dpos + (size_t)pos_offset * D;
+  EmbArgs ea = {B, L, Bc, nchunks, row0, lengths, part};
+  if (row0) {                        // ragged documents: a (position, chunk) no document reaches is not written by the kernel
+    hipError_t e = hipMemsetAsync(part, 0, (size_t)nchunks * L * D * sizeof(float), st);
+    if (e != hipSuccess) { mts_set_error("embed_layernorm_bwd: hipMemsetAsync: %s", hipGetErrorString(e)); return MTS_ERR_LAUNCH; }
+  }
+  dispatch_nv8(nv, [&](auto nvc) {
+    constexpr int NV = decltype(nvc)::value;
+    if (D == NV * 256)
+      hipLaunchKernelGGL((ln_bwd_kernel<T, NV, false, true, 0, true>), dim3(blocks), dim3(64 * ROW_WAVES), 0, st, (const T*)pre, (const T*)dh,
+                         (const float*)nullptr, (const float*)nullptr, 0, gamma, mean, rstd, n_rows, D, (T*)nullptr, slabs, ea);
+    else
+      hipLaunchKernelGGL((ln_bwd_kernel<T, NV, false, false, 0, true>), dim3(blocks), dim3(64 * ROW_WAVES), 0, st, (const T*)pre, (const T*)dh,
+                         (const float*)nullptr, (const float*)nullptr, 0, gamma, mean, rstd, n_rows, D, (T*)nullptr, slabs, ea);
+  });
+  SlabOuts so = {{dgamma, dbeta, nullptr, nullptr, nullptr, nullptr}, -1, 0};
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(D, SR_COLS), 2), dim3(256), 0, st, (const float*)slabs, blocks, 2, D, so);
+  hipLaunchKernelGGL(pos_sum_kernel, dim3(ceil_div(D, 32)), dim3(256), 0, st, (const float*)part, nchunks, L, D, out_rows, dtype0);
+  MTS_LAUNCH_CHECK("embed_layernorm_bwd");
+  return MTS_OK;
+}
+
+extern "C" int mts_embed_layernorm_bwd(void* stream, int dtype, int B, int L, int D, const void* pre, const void* dh, const float* gamma,
+                                       const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dtype0, float* dpos,
+                                       int pos_offset, const int32_t* row0, const int32_t* lengths, int n_rows, void* workspace, size_t workspace_bytes) {
+  MTS_CHECK_ARG(B > 0 && L > 0 && D > 0 && pre && dh && gamma && mean && rstd && dgamma && dbeta && dtype0 && dpos && workspace,
+                "mts_embed_layernorm_bwd: bad arguments");
+  MTS_CHECK_ARG(!row0 || (lengths && n_rows > 0 && n_rows <= B * L), "mts_embed_layernorm_bwd: packed form needs lengths and 0 < n_rows <= B*L");
+  if (workspace_bytes < mts_embed_layernorm_bwd_workspace(B, L, D)) { mts_set_error("mts_embed_layernorm_bwd: workspace too small"); return MTS_ERR_WORKSPACE; }
+  const int rows = row0 ? n_rows : B * L;
+  if (dtype == MTS_F32)
+    return emb_bwd_launch<float>((hipStream_t)stream, B, L, D, pre, dh, gamma, mean, rstd, dgamma, dbeta, dtype0, dpos, pos_offset, row0, lengths, rows, (float*)workspace);
+  if (dtype == MTS_BF16)
+    return emb_bwd_launch<bf16_t>((hipStream_t)stream, B, L, D, pre, dh, gamma, mean, rstd, dgamma, dbeta, dtype0, dpos, pos_offset, row0, lengths, rows, (float*)workspace);
+  mts_set_error("mts_embed_layernorm_bwd: bad dtype %d", dtype);
   return MTS_ERR_INVALID;
 }
 
@@ -748,8 +1029,8 @@ extern "C" int mts_head_bwd_params(void* stream, int dtype, int rows, int D, int
   } else { mts_set_error("mts_head_bwd_params: bad dtype %d", dtype); return MTS_ERR_INVALID; }
   float* rowp[4] = {nullptr, nullptr, nullptr, nullptr};
   for (int c = 0; c < n_out; ++c) rowp[c] = dw + (size_t)c * D;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(D, SR_COLS), 5), dim3(256), 0, st, (const float*)partial, blocks, 5, D, rowp[0], rowp[1],
-                     rowp[2], rowp[3], db, n_out);
+  SlabOuts so = {{rowp[0], rowp[1], rowp[2], rowp[3], db, nullptr}, 4, n_out};
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(D, SR_COLS), 5), dim3(256), 0, st, (const float*)partial, blocks, 5, D, so);
   MTS_LAUNCH_CHECK("mts_head_bwd_params");
   return MTS_OK;
 }

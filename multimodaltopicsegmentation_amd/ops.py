@@ -150,18 +150,32 @@ def embed_layernorm_fwd(x, pos, pos_offset, type0, gamma, beta, eps, y, pre, mea
 
 
 def layernorm_fwd(x, gamma, beta, eps, y, mean, rstd, head_w=None, head_b=None, scores=None):
+    """y may be None with a fused head: only the scores and the statistics are produced."""
     rows, D = x.shape
     n_out = head_w.shape[0] if head_w is not None else 0
     check(lib.mts_layernorm_fwd(stream_ptr(), dtype_code(x.dtype), rows, D, ptr(x), ptr(gamma), ptr(beta), eps, ptr(y),
                                 ptr(mean), ptr(rstd), ptr(head_w), ptr(head_b), n_out, ptr(scores)))
 
 
-def layernorm_bwd(x, dy, gamma, mean, rstd, dx, dgamma, dbeta, dxsum=None, dlogit=None, head_w=None):
+def layernorm_bwd(x, dy, gamma, mean, rstd, dx, dgamma, dbeta, dxsum=None, dlogit=None, head_w=None, beta=None, dhead_w=None, dhead_b=None):
+    """dhead_w / dhead_b (with beta): the fused head's parameter gradients come out of the same pass (n_out <= 2)."""
     rows, D = x.shape
     ws = _scratch(lib.mts_layernorm_bwd_workspace(D), x.device, 'ln_bwd')
     n_out = head_w.shape[0] if head_w is not None else 0
     check(lib.mts_layernorm_bwd(stream_ptr(), dtype_code(x.dtype), rows, D, ptr(x), ptr(dy), ptr(dlogit), ptr(head_w), n_out,
-                                ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(dxsum), ptr(ws)))
+                                ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(dxsum), ptr(ws),
+                                ptr(beta), ptr(dhead_w), ptr(dhead_b)))
+
+
+def embed_layernorm_bwd(pre, dh, gamma, mean, rstd, B, Lq, dgamma, dbeta, dtype0, dpos, pos_offset, row0=None, lengths=None):
+    """Embedding block backward in one pass: dgamma / dbeta / dtype0 and rows pos_offset .. pos_offset + Lq - 1 of dpos are
+    overwritten; the pre-LayerNorm gradient is never stored."""
+    rows, D = pre.shape
+    nb = lib.mts_embed_layernorm_bwd_workspace(B, Lq, D)
+    ws = _scratch(nb, pre.device, 'emb_bwd')
+    check(lib.mts_embed_layernorm_bwd(stream_ptr(), dtype_code(pre.dtype), B, Lq, D, ptr(pre), ptr(dh), ptr(gamma), ptr(mean), ptr(rstd),
+                                      ptr(dgamma), ptr(dbeta), ptr(dtype0), ptr(dpos), pos_offset, ptr(row0),
+                                      ptr(lengths) if row0 is not None else None, rows if row0 is not None else 0, ptr(ws), nb))
 
 
 def embed_bwd(dpre, B, Lq, dpos, pos_offset, row0=None, lengths=None):

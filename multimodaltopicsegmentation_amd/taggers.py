@@ -219,7 +219,7 @@ class _TaggerBase(FlatModule):
         first, last = names[key]
         return self._wspan(flat, first, last, rows, cols)
 
-    def _band_layer_fwd(self, names, tag, h, lengths_i32, B, Lq, N, radius, row0, pdrop, pattn, head=None):
+    def _band_layer_fwd(self, names, tag, h, lengths_i32, B, Lq, N, radius, row0, pdrop, pattn, head=None, store_out=True):
         """post-LN layer: a = LN(dropout(ctx Wo^T + bo) + h), out = LN(dropout(act(a W1^T + b1) W2^T + b2) + a), ctx = band
         attention over q|k|v = h Wqkv^T + b (q scaled by 1/sqrt(hd)).  modeling_longformer.py:482-640,1061-1172 /
         RestrictedTransformerLayer.py:269-310.  head = (w, b, scores): tagger head fused into the last LayerNorm."""
@@ -272,7 +272,9 @@ class _TaggerBase(FlatModule):
             ops.dropout_fwd(tmp, s2, pdrop, self._drop_seed(), mask=m2, residual=a1)
         else:
             ops.linear_fwd(f, w2, b2, s2, residual=a1)
-        hout = ws.get(f'hout{tag}', N, D, dt, dev)
+        # store_out = False (with a fused head): the layer's output is fed to the head and NOT written -- the native training step never
+        # reads it again (the LayerNorm backward recomputes it for the head's weight gradient), forward() only wants the scores
+        hout = ws.get(f'hout{tag}', N, D, dt, dev) if (store_out or head is None) else None
         mean2 = ws.get(f'mean2_{tag}', N, 1, torch.float32, dev)
         rstd2 = ws.get(f'rstd2_{tag}', N, 1, torch.float32, dev)
         ops.layernorm_fwd(s2, self._lt(pf, names, 'ln2w', 1, D).view(-1), self._lt(pf, names, 'ln2b', 1, D).view(-1), self.ln_eps,
@@ -281,7 +283,7 @@ class _TaggerBase(FlatModule):
         return dict(hin=h, qkv=qkv, ctx=ctx, probs=probs, s1=s1, a1=a1, mean1=mean1, rstd1=rstd1, u=u, f=f, s2=s2, hout=hout,
                     mean2=mean2, rstd2=rstd2, radius=radius, slots=slots, m1=m1, m2=m2, pattn=pattn, aseed=aseed, fused_ffn=fused)
 
-    def _band_layer_bwd(self, names, S, dh, lengths_i32, B, Lq, N, pdrop, row0, wgrad, tail_end, head=None, slot=0):
+    def _band_layer_bwd(self, names, S, dh, lengths_i32, B, Lq, N, pdrop, row0, wgrad, tail_end, head=None, slot=0, head_grads=None):
         """Gradients of one layer into grad_flat; returns d(layer input).  dh: gradient wrt the layer output (None when only the
         fused head contributes); head = (dscores, head_w): the tagger head's data gradient is formed inside the LayerNorm backward.
         wgrad(dy, x, gview): the caller's weight-gradient launcher (may run on a side stream).  tail_end: end offset of the span
@@ -289,14 +291,17 @@ class _TaggerBase(FlatModule):
         dt = self.compute_dtype
         D, F, H = self.embedding_dim, self._ffp, self.nheads
         ws, lay = self._ws, self._layout
-        dev = S['hout'].device
+        dev = S['s2'].device
         wf, pf = self._weights(), self._flat
         g = self.grad_flat()
         Gv = lambda key, rows, cols: self._lt(g, names, key, rows, cols)
         ds2 = ws.get('ds2', N, D, dt, dev)
+        # head_grads = (dW_head, db_head): the head's parameter gradients come out of this pass too (last layer, dh is None)
         ops.layernorm_bwd(S['s2'], dh, self._lt(pf, names, 'ln2w', 1, D).view(-1), S['mean2'], S['rstd2'], ds2,
                           Gv('ln2w', 1, D).view(-1), Gv('ln2b', 1, D).view(-1), dxsum=Gv('b2', 1, D).view(-1),
-                          dlogit=head[0] if head else None, head_w=head[1] if head else None)
+                          dlogit=head[0] if head else None, head_w=head[1] if head else None,
+                          beta=self._lt(pf, names, 'ln2b', 1, D).view(-1) if head_grads else None,
+                          dhead_w=head_grads[0] if head_grads else None, dhead_b=head_grads[1] if head_grads else None)
         # FFN down:  s2 = dropout(f W2^T + b2) + a1
         ds2d = ds2
         if pdrop:
@@ -496,8 +501,9 @@ class Transformer_segmenter(_TaggerBase):
                 'ln2b': one(lp + 'output.LayerNorm.bias')}
 
     # ---- native forward / backward ------------------------------------------------------------------
-    def _forward_native(self, xs, lengths_i32, want_grad_state=True, pack=None):
-        """pack = {'row_src', 'row0', 'n'} (see _pack_plan): activations hold only the valid sentences."""
+    def _forward_native(self, xs, lengths_i32, want_grad_state=True, pack=None, need_hidden=True):
+        """pack = {'row_src', 'row0', 'n'} (see _pack_plan): activations hold only the valid sentences.
+        need_hidden = False: the last layer's output goes to the fused head only and is not written to memory."""
         xs, xs2, B, Lq, D = self._split_input(xs)
         dt, dev = self.compute_dtype, xs.device
         if D != self.embedding_dim:
@@ -531,7 +537,7 @@ class Transformer_segmenter(_TaggerBase):
             last = li == len(self.radii) - 1
             head = (self._w(pf, 'classification.weight'), self._w(pf, 'classification.bias'), scores) if last else None
             S = self._band_layer_fwd(self._layer_names(li), str(li), h, lengths_i32, B, Lq, N, radius, row0, pdrop,
-                                     self.dropout_out if self.training else 0.0, head)
+                                     self.dropout_out if self.training else 0.0, head, store_out=need_hidden or not last)
             st['layers'].append(S)
             h = S['hout']
         st['scores'] = scores if pack else scores.view(B, Lq, self.n_out)
@@ -570,26 +576,42 @@ class Transformer_segmenter(_TaggerBase):
             last = li == nl - 1
             if side is not None:
                 main.wait_stream(side)         # the previous layer's weight gradients are done with ds2 / du / ds1 / dqkv
-            if last:
+            # the head's parameter gradients: from the last layer's LayerNorm backward (no pass over the stored output, which the
+            # training forward does not even write); a head wider than two outputs keeps its own kernel
+            fuse_hg = last and self.n_out <= 2
+            if last and not fuse_hg:
                 ops.head_bwd_params(st['layers'][li]['hout'], dscores, G('classification.weight'), G('classification.bias'))
             tail_end = lay.entries[f'model.model.encoder.layer.{li + 1}.attention.self.query.weight'][0] if li + 1 < nl else g.numel()
             dh = self._band_layer_bwd(self._layer_names(li), st['layers'][li], dh, st['lengths'], B, Lq, N, st['pdrop'],
                                       st['pack']['row0'] if st['pack'] else None, wgrad, tail_end,
-                                      head=(dscores, self._w(pf, 'classification.weight')) if last else None, slot=li & 1)
+                                      head=(dscores, self._w(pf, 'classification.weight')) if last else None, slot=li & 1,
+                                      head_grads=(G('classification.weight'), G('classification.bias')) if fuse_hg else None)
         e = 'model.model.embeddings.'
         if st['pdrop']:
             ops.dropout_bwd(dh, dh, st['m0'], st['pdrop'])         # through the dropout behind the embedding LayerNorm
-        dpre = ws.get('ds2', N, D, dt, dev)
-        G(e + 'token_type_embeddings.weight').zero_()
-        # d(type row 0) = sum over all rows of dpre = the LayerNorm backward's column sum of dx
-        ops.layernorm_bwd(st['pre0'], dh, self._w(pf, e + 'LayerNorm.weight'), st['mean0'], st['rstd0'], dpre,
-                          G(e + 'LayerNorm.weight'), G(e + 'LayerNorm.bias'), dxsum=G(e + 'token_type_embeddings.weight')[0])
-        # only rows [2, L+2) of the position table ever receive a gradient: keep the rest of its gradient at the zeros it was
-        # allocated with and clear what the longest batch so far could have touched
-        self._pos_touched = max(getattr(self, '_pos_touched', 0), Lq + 2)
-        G(e + 'position_embeddings.weight')[:self._pos_touched].zero_()
-        ops.embed_bwd(dpre, B, Lq, G(e + 'position_embeddings.weight'), 2, row0=st['pack']['row0'] if st['pack'] else None,
-                      lengths=st['lengths'])
+        pos_g, type_g = G(e + 'position_embeddings.weight'), G(e + 'token_type_embeddings.weight')
+        if D <= 2048:
+            # one pass: LayerNorm backward + the sums that are all anybody wants of its dx -- over the documents of each position into
+            # rows [2, L + 2) of the position table, over all rows into token-type row 0 (both OVERWRITTEN; type row 1 is never touched
+            # and keeps the zero it was allocated with).  A longer batch earlier may have left rows beyond L + 2: cleared once.
+            prev = getattr(self, '_pos_touched', 0)
+            if prev > Lq + 2:
+                pos_g[Lq + 2:prev].zero_()
+            self._pos_touched = Lq + 2
+            ops.embed_layernorm_bwd(st['pre0'], dh, self._w(pf, e + 'LayerNorm.weight'), st['mean0'], st['rstd0'], B, Lq,
+                                    G(e + 'LayerNorm.weight'), G(e + 'LayerNorm.bias'), type_g[0], pos_g, 2,
+                                    row0=st['pack']['row0'] if st['pack'] else None, lengths=st['lengths'])
+        else:
+            dpre = ws.get('ds2', N, D, dt, dev)
+            type_g.zero_()
+            # d(type row 0) = sum over all rows of dpre = the LayerNorm backward's column sum of dx
+            ops.layernorm_bwd(st['pre0'], dh, self._w(pf, e + 'LayerNorm.weight'), st['mean0'], st['rstd0'], dpre,
+                              G(e + 'LayerNorm.weight'), G(e + 'LayerNorm.bias'), dxsum=type_g[0])
+            # only rows [2, L+2) of the position table ever receive a gradient: keep the rest of its gradient at the zeros it was
+            # allocated with and clear what the longest batch so far could have touched
+            self._pos_touched = max(getattr(self, '_pos_touched', 0), Lq + 2)
+            pos_g[:self._pos_touched].zero_()
+            ops.embed_bwd(dpre, B, Lq, pos_g, 2, row0=st['pack']['row0'] if st['pack'] else None, lengths=st['lengths'])
         # embeddings: only the position rows a batch of this length can touch, then type row + LayerNorm
         D_ = self.embedding_dim
         if side is not None:
@@ -644,7 +666,7 @@ class Transformer_segmenter(_TaggerBase):
         dev = x1.device
         li32 = self._prep_lengths(lengths, B, Lq, dev)
         pack = self._pack_plan(lengths, B, Lq, dev)
-        st = self._forward_native(xs, li32, pack=pack)
+        st = self._forward_native(xs, li32, pack=pack, need_hidden=False)
         tg = tags.to(device=dev, dtype=torch.float32).contiguous()
         loss_out = torch.empty(2, dtype=torch.float32, device=dev)
         dsc = self._ws.get('dscores', st['N'], self.n_out, torch.float32, dev) if want_grad else None
@@ -692,7 +714,7 @@ class Transformer_segmenter(_TaggerBase):
         li_s.copy_(li32)
 
         def run():
-            st = self._forward_native(xs_s, li_s)
+            st = self._forward_native(xs_s, li_s, need_hidden=False)
             ops.greedy_decode(st['scores'], li_s, th, tags)
             return st['scores']
         self._weights()                                   # the bf16 mirror is refreshed OUTSIDE the graph (a cast inside would replay forever)
@@ -729,7 +751,7 @@ class Transformer_segmenter(_TaggerBase):
                 L.check_async()
                 lens = [int(v) for v in (lenghts.tolist() if lenghts is not None else [Lq] * B)]
                 return scores, [tags_h[i, :lens[i]].tolist() for i in range(B)]
-            st = self._forward_native(xs, li32)
+            st = self._forward_native(xs, li32, need_hidden=False)
             scores = st['scores'].clone()
             tags = self._decode(scores, li32, lenghts, threshold)
         return scores, tags

@@ -1,0 +1,109 @@
+"""Round-3 forms of the LayerNorm backward (csrc/norm.hip), each against an fp64 autograd reference of the same op:
+
+  * mts_embed_layernorm_bwd: embedding LayerNorm backward + position-table / token-type gradient in ONE pass (the pre-LN gradient is
+    never stored) -- padded and packed (ragged) batches, chunked and un-chunked document loops, D = 64 (bounds-checked slots),
+    256, 1792 (the BASELINE width);
+  * mts_layernorm_bwd with dhead_w / dhead_b: the fused head's parameter gradients from the last layer's LayerNorm backward, with the
+    forward NOT storing its output (mts_layernorm_fwd y = NULL).
+Reference arithmetic: modeling_longformer.py:402-426 (embeddings), :1127-1131 (output LayerNorm), models/CRF.py:579 (head).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _ln(x, g, b, eps):
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * g + b
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,L,D,ragged', [(5, 19, 64, False), (5, 19, 64, True), (3, 128, 256, True), (64, 256, 1792, False), (9, 300, 1792, True),
+                                          (2, 2100, 256, True)])
+def test_embedding_backward_in_one_pass(dtype, B, L, D, ragged):
+    from multimodaltopicsegmentation_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + L + D)
+    lengths = torch.full((B,), L, dtype=torch.int64)
+    if ragged:
+        lengths = torch.randint(1, L + 1, (B,), generator=g)
+        lengths[0] = L
+        if B > 2:
+            lengths[1] = 1
+    if ragged:                                   # packed rows: document after document
+        row0 = torch.zeros(B, dtype=torch.int64)
+        row0[1:] = torch.cumsum(lengths, 0)[:-1]
+        n = int(lengths.sum())
+        pos_of = torch.cat([torch.arange(k) for k in lengths.tolist()])
+    else:
+        row0, n = None, B * L
+        pos_of = torch.arange(L).repeat(B)
+    pre = torch.randn(n, D, generator=g).to(dtype)
+    dh = (torch.randn(n, D, generator=g) * 0.3).to(dtype)
+    gamma = 1.0 + 0.1 * torch.randn(D, generator=g)
+    eps = 1e-12
+    # statistics exactly as the forward saves them (fp32 from the stored pre)
+    pf = pre.float()
+    mean = pf.mean(-1)
+    rstd = 1.0 / torch.sqrt(((pf - mean[:, None]) ** 2).mean(-1) + eps)
+    # fp64 reference
+    p64 = pre.double().requires_grad_(True)
+    g64 = gamma.double().requires_grad_(True)
+    b64 = torch.zeros(D, dtype=torch.float64, requires_grad=True)
+    (_ln(p64, g64, b64, eps) * dh.double()).sum().backward()
+    dpre = p64.grad
+    ref_pos = torch.zeros(L, D, dtype=torch.float64).index_add_(0, pos_of, dpre)
+    ref_type = dpre.sum(0)
+
+    P = 7 + L                                    # a position table with rows on either side of [2, L + 2)
+    dpos = torch.full((P, D), 7.0, device=DEV)   # garbage: the rows of this batch are OVERWRITTEN, the others untouched
+    dgam, dbet, dtyp = (torch.full((D,), 9.0, device=DEV) for _ in range(3))
+    ops.embed_layernorm_bwd(pre.to(DEV), dh.to(DEV), gamma.to(DEV), mean.to(DEV), rstd.to(DEV), B, L, dgam, dbet, dtyp, dpos, 2,
+                            row0=row0.to(DEV, torch.int32) if ragged else None, lengths=lengths.to(DEV, torch.int32))
+    torch.cuda.synchronize()
+    tol = 2e-5 if dtype == torch.float32 else 2e-5      # inputs are exact in either dtype; the pass itself is fp32 throughout
+    for name, got, ref in (('dgamma', dgam, g64.grad), ('dbeta', dbet, b64.grad), ('dtype0', dtyp, ref_type), ('dpos', dpos[2:L + 2], ref_pos)):
+        d = (got.cpu().double() - ref).abs().max().item()
+        assert d <= tol * max(1.0, ref.abs().max().item()), (name, d, ref.abs().max().item())
+    assert torch.all(dpos[:2] == 7.0) and torch.all(dpos[L + 2:] == 7.0)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('rows,D,n_out', [(37, 64, 1), (37, 64, 2), (300, 256, 2), (4096, 1792, 1), (1000, 1792, 2), (70, 2304, 1)])
+def test_head_parameter_gradients_from_the_layernorm_backward(dtype, rows, D, n_out):
+    from multimodaltopicsegmentation_amd import ops
+    g = torch.Generator().manual_seed(rows + D + n_out)
+    x = torch.randn(rows, D, generator=g).to(dtype)
+    gamma, beta = 1.0 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    hw, hb = torch.randn(n_out, D, generator=g) / D ** 0.5, torch.randn(n_out, generator=g)
+    dlog = torch.randn(rows, n_out, generator=g) * 0.1
+    eps = 1e-12
+    xd = x.to(DEV)
+    mean, rstd = torch.empty(rows, 1, device=DEV), torch.empty(rows, 1, device=DEV)
+    scores = torch.empty(rows, n_out, device=DEV)
+    # forward WITHOUT storing y: the head's scores must equal those of a forward that stores it
+    ops.layernorm_fwd(xd, gamma.to(DEV), beta.to(DEV), eps, None, mean, rstd, head_w=hw.to(DEV), head_b=hb.to(DEV), scores=scores)
+    y = torch.empty(rows, D, dtype=dtype, device=DEV)
+    scores2 = torch.empty_like(scores)
+    ops.layernorm_fwd(xd, gamma.to(DEV), beta.to(DEV), eps, y, torch.empty_like(mean), torch.empty_like(rstd), head_w=hw.to(DEV), head_b=hb.to(DEV),
+                      scores=scores2)
+    assert torch.equal(scores, scores2)
+    dx = torch.empty(rows, D, dtype=dtype, device=DEV)
+    dgam, dbet, dxs, dhw = (torch.full((k, D), 3.0, device=DEV) for k in (1, 1, 1, n_out))
+    dhb = torch.full((n_out,), 3.0, device=DEV)
+    ops.layernorm_bwd(xd, None, gamma.to(DEV), mean, rstd, dx, dgam.view(-1), dbet.view(-1), dxsum=dxs.view(-1), dlogit=dlog.to(DEV),
+                      head_w=hw.to(DEV), beta=beta.to(DEV), dhead_w=dhw, dhead_b=dhb)
+    torch.cuda.synchronize()
+    x64 = x.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    w64, hb64 = hw.double().requires_grad_(True), hb.double().requires_grad_(True)
+    sc = _ln(x64, g64, b64, eps) @ w64.t() + hb64
+    (sc * dlog.double()).sum().backward()
+    bf = dtype == torch.bfloat16
+    assert (scores.cpu().double() - sc.detach()).abs().max().item() <= (3e-2 if bf else 2e-5)
+    for name, got, ref, tol in (('dx', dx.float(), x64.grad, 1e-2 if bf else 2e-5), ('dgamma', dgam.view(-1), g64.grad, 2e-5), ('dbeta', dbet.view(-1), b64.grad, 2e-5),
+                                ('dxsum', dxs.view(-1), x64.grad.sum(0), 2e-2 if bf else 2e-5), ('dhead_w', dhw, w64.grad, 2e-5), ('dhead_b', dhb, hb64.grad, 2e-5)):
+        d = (got.cpu().double() - ref).abs().max().item()
+        assert d <= tol * max(1.0, ref.abs().max().item()), (name, d, ref.abs().max().item())

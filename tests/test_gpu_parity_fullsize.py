@@ -80,6 +80,8 @@ def test_transformer_64x256x1792_bf16_against_the_oracle():
                                                compute_dtype='bf16', max_position_embedding=Lq + 2, seed=21).to(DEV))
     x, _, y, lengths = _full_batch(B, Lq, D, 22)
     xd, yd = x.to(DEV), y.to(DEV)
+    ops._plan_cache.clear()                                  # timer labels = the plan of a shape's FIRST launch in this process: forget those
+                                                             # of earlier tests that forced a tile through mts_set_option
     m.loss_and_grad(xd, lengths, yd, True)                   # first call: the planner's choice per shape is recorded (timer labels)
     timer = ops.KernelTimer()
     ops.TIMER = timer
