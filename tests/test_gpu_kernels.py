@@ -119,7 +119,8 @@ def test_gemm_bf16_tile_224(ops, layout, M, N, K):
 
 
 @pytest.mark.parametrize('layout', ['NT', 'NN', 'TT'])
-@pytest.mark.parametrize('M,N,K', [(512, 448, 64), (512, 448, 128), (512, 448, 192), (256, 224, 256), (768, 1792, 1792), (1000, 224, 704)])
+@pytest.mark.parametrize('M,N,K', [(512, 448, 64), (512, 448, 128), (512, 448, 192), (256, 224, 256), (768, 1792, 1792), (1000, 224, 704), (1024, 5376, 1792),
+                                   (2048, 1792, 5376)])
 def test_gemm_224_barrier_schedules_agree_bitwise(ops, layout, M, N, K):
     """The two K-loop schedules of the 256x224 kernel (barrier in the middle of the K-tile: default for NT / NN / TT; at its end:
     gemm_variant 5) accumulate every output element in the same order -- results must be identical bit for bit, with 1, 2 and many
@@ -133,7 +134,7 @@ def test_gemm_224_barrier_schedules_agree_bitwise(ops, layout, M, N, K):
     outs = {}
     try:
         L.check(L.lib.mts_set_option(b'gemm_tile', 224))
-        for variant in (0, 5):
+        for variant in (0, 5, 7):                 # 7: the four-wave register-staged kernel (gemm224r.hip) where it applies (bf16 C, M % 256 == 0, K >= 128)
             L.check(L.lib.mts_set_option(b'gemm_variant', variant))
             o16 = torch.full((M, N), float('nan'), dtype=torch.bfloat16, device=DEV)
             ops.gemm(code, A, Bm, o16, M=M, N=N, K=K, bias=bias, residual=res)
@@ -145,6 +146,8 @@ def test_gemm_224_barrier_schedules_agree_bitwise(ops, layout, M, N, K):
         L.check(L.lib.mts_set_option(b'gemm_tile', 0))
     assert torch.equal(outs[0][0].view(torch.int16), outs[5][0].view(torch.int16))
     assert torch.equal(outs[0][1].view(torch.int32), outs[5][1].view(torch.int32))
+    assert torch.equal(outs[0][0].view(torch.int16), outs[7][0].view(torch.int16))
+    assert torch.equal(outs[0][1].view(torch.int32), outs[7][1].view(torch.int32))
     assert not torch.isnan(outs[0][1]).any()
     ref = a.double() @ b.double().t()
     _close(outs[0][1], ref, 1e-4, 1e-4 * math.sqrt(K), f'{layout} mid-tile barrier fp32 C')
