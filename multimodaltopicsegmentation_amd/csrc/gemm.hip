@@ -685,6 +685,7 @@ static thread_local int g_big_min_k = 256;                // smallest K the big-
 static thread_local int g_gemm_variant = 0;               // A/B switch of the big-tile kernels (GemmArgs::variant)
 void mts_lstm_pair_set_spin_limit(int n);   // lstm_pair.hip
 void mts_lstm_pair_set_max_pairs(int n);
+void mts_lstm_pair_set_parts(int n);
 extern "C" int mts_set_option(const char* key, int value) {
   if (!key) return MTS_ERR_INVALID;
   if (!strcmp(key, "gemm_tile")) { g_tile_mode = value; return MTS_OK; }
@@ -699,6 +700,7 @@ extern "C" int mts_set_option(const char* key, int value) {
   if (!strcmp(key, "band_mfma")) { mts_band_set_mfma(value); return MTS_OK; }
   if (!strcmp(key, "lstm_pair_spin_limit")) { mts_lstm_pair_set_spin_limit(value); return MTS_OK; }
   if (!strcmp(key, "lstm_pair_max_pairs")) { mts_lstm_pair_set_max_pairs(value); return MTS_OK; }
+  if (!strcmp(key, "lstm_parts")) { mts_lstm_pair_set_parts(value); return MTS_OK; }
   mts_set_error("mts_set_option: unknown key %s", key);
   return MTS_ERR_INVALID;
 }

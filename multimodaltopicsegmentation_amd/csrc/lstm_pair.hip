@@ -360,10 +360,17 @@ bool mts_lstm_pair_supported(int dtype, int H) {
 
 // workspace: packed weights (bf16) | exchange granules | status word
 static size_t pair_wbytes(int H, int ndir) { return align_up((size_t)ndir * 4 * H * H * 2, 256); }
-static size_t pair_xbytes(int B, int ndir) { return align_up((size_t)ceil_div(B, LP_DOCS * LP_GROUPS) * ndir * LP_GROUPS * 2 * 2 * 1024 * sizeof(u64), 256); }
+// exchange granules per (16 documents, direction): pair form 2 halves x 2 parities x 1024; quad forward 4 x 2 x 512 (the same);
+// quad backward 4 sources x 4 destinations x 2 parities x 512 -- the buffer is sized for the largest
+static size_t pair_xbytes(int B, int ndir) { return align_up((size_t)ceil_div(B, LP_DOCS * LP_GROUPS) * ndir * LP_GROUPS * 4 * 4 * 2 * 512 * sizeof(u64), 256); }
 // ... | status word (256 B) | dump area (stores of lanes whose document has ended)
 #define LP_DUMP_BYTES 16384
 size_t mts_lstm_pair_workspace(int B, int H, int ndir) { return pair_wbytes(H, ndir) + pair_xbytes(B, ndir) + 256 + LP_DUMP_BYTES; }
+
+static thread_local int g_lstm_parts = 4;          // mts_set_option("lstm_parts", 2 | 4): CU pair or CU quad form of the recurrences
+void mts_lstm_pair_set_parts(int n) { g_lstm_parts = (n == 2) ? 2 : 4; }
+static int lstm_quad_fwd_launch(hipStream_t st, int B, int L, int H, int ndir, const void* xproj, const bf16_t* wpk, const float* b_hh, const int32_t* lengths,
+                                void* out, void* gates, float* cells, u64* xch, unsigned* status);
 
 int mts_lstm_pair_fwd(hipStream_t st, int B, int L, int H, int ndir, const void* xproj, const float* w_hh, const float* b_hh,
                       const int32_t* lengths, void* out, void* gates, float* cells, void* ws) {
@@ -387,6 +394,7 @@ int mts_lstm_pair_fwd(hipStream_t st, int B, int L, int H, int ndir, const void*
   static int xflags = -1;
   if (xflags < 0) { const char* e = getenv("MTS_LSTM_EXP"); xflags = e ? atoi(e) : 0; }
   if (int rc = lp_ensure_sticky()) return rc;
+  if (g_lstm_parts == 4) return lstm_quad_fwd_launch(st, B, L, H, ndir, xproj, wpk, b_hh, lengths, out, gates, cells, xch, status);
   // at most g_max_pairs pairs per launch (see "Safety" at the top): documents [b0, b0 + bc) per launch, rows are b * L + i
   const int docs_per_launch = std::max(1, g_max_pairs / ndir) * LP_DOCS * LP_GROUPS;
   for (int b0 = 0; b0 < B; b0 += docs_per_launch) {
@@ -617,6 +625,429 @@ __global__ __launch_bounds__(KS * 64, 2) void lstm_bwd_pair_kernel(int B, int L,
       for (int gt = 0; gt < 4; ++gt) *reinterpret_cast<uint2*>(dxproj + ((size_t)bdoc * L + t) * ldx + (size_t)d * 4 * H + gt * H + u) = make_uint2(0, 0);
 }
 
+// =====================================================================================================
+// "CU quad" form of the forward recurrence: the hidden units of one (16 documents, direction) are split over FOUR workgroups
+// (64 units each, 4 waves = ONE per SIMD, all four gate tiles of a wave's 16 units in registers: 128 VGPRs).  Against the pair
+// form a step's matrix-core time and gate math halve (32 MFMAs + one wave's elementwise work per SIMD instead of two waves' worth)
+// and nothing of W_hh lives in LDS; what grows is the exchange: every workgroup posts its quarter of the new h (16 x 64 bf16 = 512
+// tagged granules) and polls the three other quarters (6 granules per thread instead of 2).  The exchange latency itself (store ->
+// L2 -> poll, ~1 us) is unchanged, so the dependent step is  ~0.25 (MFMA) + ~0.3 (gates) + ~1.0 (hand-off) + LDS / barrier.
+// Same packed weights, same exchange-buffer size and the same safety rules as the pair form (bounded polls, reported timeouts, a
+// launch never holds more workgroups than stay co-resident: LQ_MAX_QUADS x 4 = 128).
+// =====================================================================================================
+#define LQ_MAX_QUADS 32
+template <int KS>
+__global__ __launch_bounds__(256, 1) void lstm_fwd_quad_kernel(int B, int L, int ndir, int nquads, const bf16_t* __restrict__ xproj,
+                                                               const bf16_t* __restrict__ wpk, const float* __restrict__ bhh,
+                                                               const int32_t* __restrict__ lengths, bf16_t* __restrict__ out,
+                                                               bf16_t* __restrict__ gates, float* __restrict__ cells, u64* __restrict__ xch,
+                                                               unsigned* __restrict__ status, char* __restrict__ dump, unsigned spin_limit,
+                                                               unsigned* __restrict__ sticky) {
+  constexpr int H = KS * 32, HQ = H / 4, NT = 256, HROW = (H + 8) * 2;
+  static_assert(KS == 8, "H = 256");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* hbuf = smem;                                     // [parity][16][HROW]
+  float* blds = reinterpret_cast<float*>(smem + 2 * LP_DOCS * HROW);   // [4][HQ] this quarter's recurrent bias
+  // quad index and part from a 1-D grid: the four parts of a quad are 8 block ids apart (same XCD under round-robin dispatch)
+  const int chunk = blockIdx.x / 32, within = blockIdx.x % 32;
+  const int p = within / 8, quad = chunk * 8 + within % 8;
+  if (quad >= nquads) return;
+  const int gx = quad / ndir, d = quad % ndir;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int doc = lane & 15, g4 = lane >> 4;
+  const int ul = w * 16 + 4 * g4;                        // this lane's 4 units, within the quarter
+  const int u = p * HQ + ul;                             // ... within H
+  const int ldx = ndir * 4 * H, ldo = ndir * H;
+
+  // resident weights: all four gate tiles x 8 k-steps of the wave's 16 units.  Packed as for the pair form: units p*64 + w*16 .. are
+  // "half p >> 1, wave (p & 1) * 4 + w" there.
+  bf16x8 wreg[4][KS];
+  {
+    const bf16_t* base = wpk + ((((size_t)d * 2 + (p >> 1)) * KS + ((p & 1) * 4 + w)) * 4 * KS * 64) * 8;
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) wreg[gt][ks] = *reinterpret_cast<const bf16x8*>(base + ((size_t)(gt * KS + ks) * 64 + lane) * 8);
+  }
+  for (int i = tid; i < 4 * HQ; i += NT) blds[i] = bhh ? bhh[(size_t)d * 4 * H + (i / HQ) * H + p * HQ + (i % HQ)] : 0.f;
+
+  const int bdoc = gx * LP_DOCS + doc;
+  const int len = (bdoc < B) ? (lengths ? min(lengths[bdoc], L) : L) : 0;
+  int maxlen = len;
+#pragma unroll
+  for (int off = 1; off < 16; off <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
+
+  // exchange areas: xch[quad][part][parity][512 granules]; granule k2 of (document, unit quad q = ul / 4) sits at k2 * 256 + q * 16 + doc
+  auto xarea = [&](int part, int par) { return xch + (((size_t)quad * 4 + part) * 2 + par) * 512; };
+
+  float c[4] = {0.f, 0.f, 0.f, 0.f};
+  uint2 hq = make_uint2(0, 0);
+  uint2 xb[2][4];                                        // x rows of the next TWO steps, by step parity
+  for (int i = tid; i < 2 * LP_DOCS * HROW / 16; i += NT) reinterpret_cast<uint4*>(hbuf)[i] = make_uint4(0, 0, 0, 0);
+
+  const size_t b0 = (size_t)min(bdoc, B - 1) * L;
+  const size_t grow0 = b0 * ldx + (size_t)d * 4 * H + u, orow0 = b0 * ldo + (size_t)d * H + u;
+  const bf16_t* xbase = xproj + grow0;
+  auto load_x = [&](auto parc, int s) {                  // unconditional, clamped (see the pair kernel)
+    constexpr int PAR = decltype(parc)::value;
+    const int t = (d == 0) ? s : (len - 1 - s);
+    const bf16_t* src = xbase + (size_t)min(max(t, 0), L - 1) * ldx;
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt) xb[PAR][gt] = *reinterpret_cast<const uint2*>(src + gt * H);
+  };
+  bool dead = false;
+  // the three other quarters of h after step s -> LDS hbuf[(s+1)&1]; q-th partner = part (p + 1 + q) & 3
+  u64 v[3][2];
+  auto fetch_issue = [&](int s) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const u64* src = xarea((p + 1 + q) & 3, (s + 1) & 1) + tid;
+      v[q][0] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v[q][1] = __hip_atomic_load(src + 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  auto fetch = [&](int s) {
+    const unsigned epoch = (unsigned)(s + 1);
+    auto tags_ok = [&]() {
+      bool ok = true;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) ok &= ((unsigned)(v[q][0] >> 32) == epoch) & ((unsigned)(v[q][1] >> 32) == epoch);
+      return __all(ok);
+    };
+    if (!tags_ok() && !dead) {
+      unsigned spins = 0;
+#pragma clang loop unroll(disable)
+      for (;;) {
+        asm volatile("" : "+s"(spins));
+        if (++spins > spin_limit) { dead = true; if (lane == 0) lp_report_timeout(status, sticky, 1u); break; }
+        __builtin_amdgcn_s_sleep(1);
+        fetch_issue(s);
+        if (tags_ok()) break;
+      }
+    }
+    char* dst = hbuf + (((s + 1) & 1) * LP_DOCS) * HROW;
+    const int qd = tid >> 4, dd = tid & 15;              // granule tid (+ 256 k2): unit quad qd, document dd
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int part = (p + 1 + q) & 3;
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2)
+        *reinterpret_cast<unsigned*>(dst + dd * HROW + (part * HQ + qd * 4 + k2 * 2) * 2) = (unsigned)v[q][k2];
+    }
+  };
+
+  load_x(std::integral_constant<int, 0>{}, 0);
+  load_x(std::integral_constant<int, 1>{}, 1);
+  __syncthreads();
+  float bia[4][4];
+#pragma unroll
+  for (int gt = 0; gt < 4; ++gt) {
+    const float4 b4 = *reinterpret_cast<const float4*>(blds + gt * HQ + ul);
+    bia[gt][0] = b4.x; bia[gt][1] = b4.y; bia[gt][2] = b4.z; bia[gt][3] = b4.w;
+  }
+
+  auto step = [&](auto parc, int s) {
+    constexpr int PAR = decltype(parc)::value;
+    const char* hcur = hbuf + (PAR * LP_DOCS) * HROW;
+    char* hnext = hbuf + ((PAR ^ 1) * LP_DOCS) * HROW;
+    bf16x8 hf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) hf[ks] = *reinterpret_cast<const bf16x8*>(hcur + doc * HROW + (ks * 32 + 8 * g4) * 2);
+    f32x4 acc[4];
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt) acc[gt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int gt = 0; gt < 4; ++gt) acc[gt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[gt][ks], hf[ks], acc[gt], 0, 0, 0);
+    const bool active = s < len;
+    float gi[4], gf[4], gg[4], go[4];
+    {
+      float xi[4], xf[4], xg[4], xo[4], hn[4];
+      upk4(xb[PAR][0], xi); upk4(xb[PAR][1], xf); upk4(xb[PAR][2], xg); upk4(xb[PAR][3], xo);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        gi[r] = fsig2((xi[r] + bia[0][r]) + acc[0][r]);
+        gf[r] = fsig2((xf[r] + bia[1][r]) + acc[1][r]);
+        gg[r] = ftanh2((xg[r] + bia[2][r]) + acc[2][r]);
+        go[r] = fsig2((xo[r] + bia[3][r]) + acc[3][r]);
+        const float cn = gf[r] * c[r] + gi[r] * gg[r];
+        hn[r] = go[r] * ftanh2(cn);
+        c[r] = active ? cn : c[r];
+      }
+      const uint2 hnew = pk4(hn);
+      hq.x = active ? hnew.x : hq.x;
+      hq.y = active ? hnew.y : hq.y;
+    }
+    // 1) post the own quarter of the new h: LDS for this workgroup, tagged granules for the three others
+    *reinterpret_cast<uint2*>(hnext + doc * HROW + u * 2) = hq;
+    {
+      u64* mine = xarea(p, PAR ^ 1);
+      const u64 tag = (u64)(unsigned)(s + 1) << 32;
+      __hip_atomic_store(mine + (ul >> 2) * 16 + doc, tag | hq.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(mine + 256 + (ul >> 2) * 16 + doc, tag | hq.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // 2) first poll of the partners' quarters, 3) x rows two steps ahead (queued before the bulk stores), then the poll check
+    fetch_issue(s);
+    load_x(parc, s + 2);
+    fetch(s);
+    // 4) saved state for the backward pass, last (ended documents store to the dump area)
+    {
+      const int t = (d == 0) ? s : (len - 1 - s);
+      bf16_t* gp = active ? gates + grow0 + (size_t)t * ldx : reinterpret_cast<bf16_t*>(dump + tid * 16);
+      float* cptr = active ? cells + orow0 + (size_t)t * ldo : reinterpret_cast<float*>(dump + tid * 16);
+      bf16_t* optr = active ? out + orow0 + (size_t)t * ldo : reinterpret_cast<bf16_t*>(dump + tid * 16);
+      *reinterpret_cast<uint2*>(gp) = pk4(gi);
+      *reinterpret_cast<uint2*>(gp + H) = pk4(gf);
+      *reinterpret_cast<uint2*>(gp + 2 * H) = pk4(gg);
+      *reinterpret_cast<uint2*>(gp + 3 * H) = pk4(go);
+      *reinterpret_cast<float4*>(cptr) = make_float4(c[0], c[1], c[2], c[3]);
+      *reinterpret_cast<uint2*>(optr) = hq;
+    }
+    __syncthreads();
+  };
+  __builtin_amdgcn_s_waitcnt(0);
+  for (int s = 0; s < maxlen; s += 2) {
+    step(std::integral_constant<int, 0>{}, s);
+    if (s + 1 < maxlen) step(std::integral_constant<int, 1>{}, s + 1);
+  }
+  // rows >= len are exactly zero
+  if (bdoc < B)
+    for (int t = len + g4; t < L; t += 4)
+      for (int e = 0; e < 16; e += 4) *reinterpret_cast<uint2*>(out + ((size_t)bdoc * L + t) * ldo + (size_t)d * H + p * HQ + w * 16 + e) = make_uint2(0, 0);
+}
+
+static int lstm_quad_fwd_launch(hipStream_t st, int B, int L, int H, int ndir, const void* xproj, const bf16_t* wpk, const float* b_hh, const int32_t* lengths,
+                                void* out, void* gates, float* cells, u64* xch, unsigned* status) {
+  constexpr int KS = 8;
+  const size_t lds = (size_t)2 * LP_DOCS * (H + 8) * 2 + (size_t)4 * (H / 4) * sizeof(float);
+  auto k = lstm_fwd_quad_kernel<KS>;
+  const int max_quads = std::max(1, std::min(LQ_MAX_QUADS, g_max_pairs / 2));
+  const int docs_per_launch = std::max(1, max_quads / ndir) * LP_DOCS;
+  for (int b0 = 0; b0 < B; b0 += docs_per_launch) {
+    const int bc = std::min(docs_per_launch, B - b0);
+    const size_t r0 = (size_t)b0 * L;
+    if (b0 > 0 && hipMemsetAsync(xch, 0, pair_xbytes(bc, ndir) + 256, st) != hipSuccess) { mts_set_error("lstm_quad: memset failed"); return MTS_ERR_LAUNCH; }
+    const int nquads = ceil_div(bc, LP_DOCS) * ndir;
+    hipLaunchKernelGGL(k, dim3(32 * ceil_div(nquads, 8)), dim3(256), lds, st, bc, L, ndir, nquads, (const bf16_t*)xproj + r0 * ndir * 4 * H, wpk, b_hh,
+                       lengths ? lengths + b0 : nullptr, (bf16_t*)out + r0 * ndir * H, (bf16_t*)gates + r0 * ndir * 4 * H, cells + r0 * ndir * H, xch, status,
+                       (char*)status + 256, g_spin_limit, g_sticky_dev);
+  }
+  MTS_LAUNCH_CHECK("mts_lstm_fwd(quad)");
+  return MTS_OK;
+}
+
+// =====================================================================================================
+// CU-quad form of the backward recurrence (mirror of lstm_bwd_pair_kernel): part p owns the 256 gate columns of its 64 units and
+// reduces dh over them for ALL 256 units -- four 16-unit tiles per wave: its own part's (kept) and one for each partner (posted as
+// bf16 granules); a lane's dh = own partial + the three partners' partials for its (document, unit quad), polled into registers.
+// 32 MFMAs per wave and step as in the pair form, but ONE wave per SIMD and all 32 weight fragments in registers.
+// Packed weights wpkQ[d][p][w][tt][ks][lane] = 8 bf16: tile tt = 0 -> units of part p, tt = q + 1 -> part (p + 1 + q) & 3; A-fragment
+// row = unit tt-part * 64 + w * 16 + (lane & 15), k = own gate column kk = ks * 32 + 8 * (lane >> 4) + e = gate (kk / 64), unit p * 64 + kk % 64.
+// =====================================================================================================
+__global__ void lstm_pack_weights_TQ_kernel(const float* __restrict__ w_hh, bf16_t* __restrict__ wpk, int H, int ndir) {
+  const int HQ = H / 4, KT = 4 * HQ / 32;                             // 8 k-steps over the 256 own gate columns
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // over d, p, w, tt, ks, lane
+  const size_t total = (size_t)ndir * 4 * 4 * 4 * KT * 64;
+  if (idx >= total) return;
+  const int lane = idx % 64;
+  size_t r = idx / 64;
+  const int ks = r % KT; r /= KT;
+  const int tt = r % 4; r /= 4;
+  const int w = r % 4; r /= 4;
+  const int p = r % 4; r /= 4;
+  const int d = (int)r;
+  const int part = (tt == 0) ? p : ((p + tt) & 3);
+  const int j = part * HQ + w * 16 + (lane & 15);
+  bf16_t* dst = wpk + idx * 8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int kk = ks * 32 + 8 * (lane >> 4) + e;
+    const int n = (kk / HQ) * H + p * HQ + (kk % HQ);
+    dst[e] = (bf16_t)w_hh[((size_t)d * 4 * H + n) * H + j];
+  }
+}
+
+template <int KS>
+__global__ __launch_bounds__(256, 1) void lstm_bwd_quad_kernel(int B, int L, int ndir, int nquads, const bf16_t* __restrict__ wpkQ,
+                                                               const int32_t* __restrict__ lengths, const bf16_t* __restrict__ gates,
+                                                               const float* __restrict__ cells, const bf16_t* __restrict__ dout,
+                                                               bf16_t* __restrict__ dxproj, u64* __restrict__ xch, unsigned* __restrict__ status,
+                                                               char* __restrict__ dump, unsigned spin_limit, unsigned* __restrict__ sticky) {
+  static_assert(KS == 8, "H = 256");
+  constexpr int H = KS * 32, HQ = H / 4, NT = 256;
+  constexpr int KT = 4 * HQ / 32;                        // 8 k-steps over the 256 own gate columns
+  constexpr int DAROW = (4 * HQ + 8) * 2;                // bytes per da row
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* dabuf = smem;                                    // [2 (step parity)][16][DAROW] bf16
+  const int chunk = blockIdx.x / 32, within = blockIdx.x % 32;
+  const int p = within / 8, quad = chunk * 8 + within % 8;
+  if (quad >= nquads) return;
+  const int gx = quad / ndir, d = quad % ndir;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int doc = lane & 15, g4 = lane >> 4;
+  const int ul = w * 16 + 4 * g4;                        // this lane's 4 units, within the quarter
+  const int u = p * HQ + ul;                             // ... within H
+  const int ldx = ndir * 4 * H, ldo = ndir * H;
+
+  bf16x8 wreg[4][KT];
+  {
+    const bf16_t* base = wpkQ + ((((size_t)d * 4 + p) * 4 + w) * 4 * KT * 64) * 8;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int ks = 0; ks < KT; ++ks) wreg[tt][ks] = *reinterpret_cast<const bf16x8*>(base + ((size_t)(tt * KT + ks) * 64 + lane) * 8);
+  }
+
+  const int bdoc = gx * LP_DOCS + doc;
+  const int len = (bdoc < B) ? (lengths ? min(lengths[bdoc], L) : L) : 0;
+  int maxlen = len;
+#pragma unroll
+  for (int off = 1; off < 16; off <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
+
+  // exchange areas: xch[quad][src][dst][parity][512 granules]; granule k2 of the position lane `tid` owns on EITHER side sits at
+  // k2 * 256 + tid: posts and polls are contiguous 512-byte wave accesses and a poll lands in the consuming lane's registers
+  auto xarea = [&](int src, int dst, int par) { return xch + ((((size_t)quad * 4 + src) * 4 + dst) * 2 + par) * 512; };
+  for (int i = tid; i < 2 * LP_DOCS * DAROW / 4; i += NT) reinterpret_cast<unsigned*>(smem)[i] = 0u;
+
+  const size_t b0 = (size_t)min(bdoc, B - 1) * L;
+  const size_t grow0 = b0 * ldx + (size_t)d * 4 * H + u;
+  const size_t orow0 = b0 * ldo + (size_t)d * H + u;
+  auto load_in = [&](int s, PairBwdIn& in) {             // unconditional, clamped (see the pair kernels)
+    const int sc = max(s, 0);
+    const int t = min(max((d == 0) ? sc : (len - 1 - sc), 0), L - 1);
+    const int tp = min(max((d == 0) ? t - 1 : t + 1, 0), L - 1);
+    const bf16_t* gp = gates + grow0 + (size_t)t * ldx;
+    in.gi = *reinterpret_cast<const uint2*>(gp);
+    in.gf = *reinterpret_cast<const uint2*>(gp + H);
+    in.gg = *reinterpret_cast<const uint2*>(gp + 2 * H);
+    in.go = *reinterpret_cast<const uint2*>(gp + 3 * H);
+    in.dov = *reinterpret_cast<const uint2*>(dout + orow0 + (size_t)t * ldo);
+    in.ct = *reinterpret_cast<const float4*>(cells + orow0 + (size_t)t * ldo);
+    in.cp = *reinterpret_cast<const float4*>(cells + orow0 + (size_t)tp * ldo);
+  };
+  bool dead = false;
+  u64 v[3][2];
+  // the partners' partial dh for my quad, produced in their MFMAs of step s; tag = maxlen - s (>= 1)
+  auto fetch_issue = [&](int s) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const u64* src = xarea((p + 1 + q) & 3, p, s & 1) + tid;
+      v[q][0] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v[q][1] = __hip_atomic_load(src + NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  auto fetch = [&](int s) {
+    const unsigned epoch = (unsigned)(maxlen - s);
+    auto tags_ok = [&]() {
+      bool ok = true;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) ok &= ((unsigned)(v[q][0] >> 32) == epoch) & ((unsigned)(v[q][1] >> 32) == epoch);
+      return __all(ok);
+    };
+    if (!tags_ok() && !dead) {
+      unsigned spins = 0;
+#pragma clang loop unroll(disable)
+      for (;;) {
+        asm volatile("" : "+s"(spins));
+        if (++spins > spin_limit) { dead = true; if (lane == 0) lp_report_timeout(status, sticky, 2u); break; }
+        __builtin_amdgcn_s_sleep(1);
+        fetch_issue(s);
+        if (tags_ok()) break;
+      }
+    }
+  };
+
+  float dc[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x4 own = (f32x4){0.f, 0.f, 0.f, 0.f};
+  PairBwdIn in[2];
+  load_in(maxlen - 1, in[0]);
+  load_in(maxlen - 2, in[1]);
+  __syncthreads();
+
+  auto step = [&](auto parc, int s) {
+    constexpr int PAR = decltype(parc)::value;
+    char* da = dabuf + PAR * LP_DOCS * DAROW;
+    const bool active = s < len;
+    const PairBwdIn& cur = in[PAR];
+    // ---- dh = own partial + the partners' partials (fixed order) (+ dOut) -> gate pre-activation gradients ---------------------
+    float dhv[4] = {own[0], own[1], own[2], own[3]};
+    if (s + 1 <= maxlen - 1) {
+      fetch(s + 1);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const unsigned lo = (unsigned)v[q][0], hi = (unsigned)v[q][1];
+        dhv[0] += bf16_lo(lo); dhv[1] += bf16_hi(lo); dhv[2] += bf16_lo(hi); dhv[3] += bf16_hi(hi);
+      }
+    }
+    uint2 qv[4];
+    {
+      float gi[4], gf[4], gg[4], go[4], dov[4], ai[4], af[4], ag[4], ao[4];
+      upk4(cur.gi, gi); upk4(cur.gf, gf); upk4(cur.gg, gg); upk4(cur.go, go); upk4(cur.dov, dov);
+      const float ct[4] = {cur.ct.x, cur.ct.y, cur.ct.z, cur.ct.w};
+      const bool has_prev = s > 0;
+      const float cp[4] = {has_prev ? cur.cp.x : 0.f, has_prev ? cur.cp.y : 0.f, has_prev ? cur.cp.z : 0.f, has_prev ? cur.cp.w : 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float tc = ftanh2(ct[r]);
+        const float dht = dov[r] + dhv[r];
+        const float dct = dc[r] + dht * go[r] * (1.f - tc * tc);
+        ai[r] = active ? dct * gg[r] * gi[r] * (1.f - gi[r]) : 0.f;
+        af[r] = active ? dct * cp[r] * gf[r] * (1.f - gf[r]) : 0.f;
+        ag[r] = active ? dct * gi[r] * (1.f - gg[r] * gg[r]) : 0.f;
+        ao[r] = active ? dht * tc * go[r] * (1.f - go[r]) : 0.f;
+        dc[r] = active ? dct * gf[r] : dc[r];
+      }
+      qv[0] = pk4(ai); qv[1] = pk4(af); qv[2] = pk4(ag); qv[3] = pk4(ao);
+    }
+    char* dr = da + doc * DAROW + ul * 2;
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt) *reinterpret_cast<uint2*>(dr + gt * HQ * 2) = qv[gt];
+    load_in(s - 2, in[PAR]);
+    {
+      const int t = (d == 0) ? s : (len - 1 - s);
+      bf16_t* dx = active ? dxproj + grow0 + (size_t)t * ldx : reinterpret_cast<bf16_t*>(dump + tid * 16);
+#pragma unroll
+      for (int gt = 0; gt < 4; ++gt) *reinterpret_cast<uint2*>(dx + gt * H) = qv[gt];
+    }
+    __syncthreads();
+    // ---- partial dh from the own gate columns: tile 0 = my units (kept), tiles 1..3 = the partners' units (posted) ------------
+    f32x4 acc[4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks) {
+      const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(da + doc * DAROW + (ks * 32 + 8 * g4) * 2);
+#pragma unroll
+      for (int tt = 3; tt >= 0; --tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[tt][ks], bfr, acc[tt], 0, 0, 0);
+    }
+    {
+      const u64 tag = (u64)(unsigned)(maxlen - s) << 32;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        u64* dst = xarea(p, (p + 1 + q) & 3, s & 1) + tid;
+        const float vv[4] = {acc[q + 1][0], acc[q + 1][1], acc[q + 1][2], acc[q + 1][3]};
+        const uint2 pk = pk4(vv);
+        __hip_atomic_store(dst, tag | pk.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + NT, tag | pk.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    own = acc[0];
+    if (s - 1 >= 0) fetch_issue(s);
+  };
+  __builtin_amdgcn_s_waitcnt(0);
+  for (int s = maxlen - 1; s >= 0; s -= 2) {
+    step(std::integral_constant<int, 0>{}, s);
+    if (s - 1 >= 0) step(std::integral_constant<int, 1>{}, s - 1);
+  }
+  if (bdoc < B)
+    for (int t = len; t < L; ++t)
+#pragma unroll
+      for (int gt = 0; gt < 4; ++gt) *reinterpret_cast<uint2*>(dxproj + ((size_t)bdoc * L + t) * ldx + (size_t)d * 4 * H + gt * H + u) = make_uint2(0, 0);
+}
+
 // hprev[b, t] = out[b, t_prev] (zero at a document's first processed position and on padded rows), per direction
 template <typename T>
 __global__ void lstm_hprev_kernel(int B, int L, int H, int ndir, const int32_t* __restrict__ lengths, const T* __restrict__ out, T* __restrict__ hprev) {
@@ -640,12 +1071,35 @@ int mts_lstm_pair_bwd(hipStream_t st, int B, int L, int H, int ndir, const float
   u64* xch = (u64*)((char*)ws + pair_wbytes(H, ndir));
   unsigned* status = (unsigned*)((char*)xch + pair_xbytes(B, ndir));
   const int HH = H / 2, KT = 4 * HH / 32;
-  const size_t total = (size_t)ndir * 2 * KS * 2 * KT * 64;
-  hipLaunchKernelGGL(lstm_pack_weights_T_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w_hh, wpk, H, ndir);
+  const bool quad = g_lstm_parts == 4;
+  if (quad) {
+    const size_t total = (size_t)ndir * 4 * 4 * 4 * 8 * 64;
+    hipLaunchKernelGGL(lstm_pack_weights_TQ_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w_hh, wpk, H, ndir);
+  } else {
+    const size_t total = (size_t)ndir * 2 * KS * 2 * KT * 64;
+    hipLaunchKernelGGL(lstm_pack_weights_T_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w_hh, wpk, H, ndir);
+  }
   if (hipMemsetAsync(xch, 0, pair_xbytes(B, ndir) + 256, st) != hipSuccess) { mts_set_error("lstm_pair: memset failed"); return MTS_ERR_LAUNCH; }
   const size_t rows4 = (size_t)B * L * ndir * H / 4;
   hipLaunchKernelGGL(lstm_hprev_kernel<bf16_t>, dim3((unsigned)((rows4 + 255) / 256)), dim3(256), 0, st, B, L, H, ndir, lengths, (const bf16_t*)out,
                      (bf16_t*)hprev);
+  if (quad) {
+    if (int rc = lp_ensure_sticky()) return rc;
+    const size_t ldsq = (size_t)2 * LP_DOCS * ((4 * (H / 4) + 8) * 2);
+    const int max_quads = std::max(1, std::min(LQ_MAX_QUADS, g_max_pairs / 2));
+    const int docs_per_launch = std::max(1, max_quads / ndir) * LP_DOCS;
+    for (int b0 = 0; b0 < B; b0 += docs_per_launch) {
+      const int bc = std::min(docs_per_launch, B - b0);
+      const size_t r0 = (size_t)b0 * L;
+      if (b0 > 0 && hipMemsetAsync(xch, 0, pair_xbytes(bc, ndir) + 256, st) != hipSuccess) { mts_set_error("lstm_quad: memset failed"); return MTS_ERR_LAUNCH; }
+      const int nquads = ceil_div(bc, LP_DOCS) * ndir;
+      hipLaunchKernelGGL(lstm_bwd_quad_kernel<KS>, dim3(32 * ceil_div(nquads, 8)), dim3(256), ldsq, st, bc, L, ndir, nquads, (const bf16_t*)wpk,
+                         lengths ? lengths + b0 : nullptr, (const bf16_t*)gates + r0 * ndir * 4 * H, cells + r0 * ndir * H, (const bf16_t*)dout + r0 * ndir * H,
+                         (bf16_t*)dxproj + r0 * ndir * 4 * H, xch, status, (char*)status + 256, g_spin_limit, g_sticky_dev);
+    }
+    MTS_LAUNCH_CHECK("mts_lstm_bwd(quad)");
+    return MTS_OK;
+  }
   const size_t lds = (size_t)2 * LP_DOCS * ((4 * HH + 8) * 2) + (size_t)KS * (KT / 2) * 1024;
   auto k = lstm_bwd_pair_kernel<KS>;
   static std::atomic<bool> attr{false};
