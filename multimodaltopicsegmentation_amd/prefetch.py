@@ -39,7 +39,11 @@ class DevicePrefetcher:
             raise ValueError("wire_dtype must be 'fp32' or 'bf16'")
         if depth < 1:
             raise ValueError('depth must be >= 1')
-XX
+        self.batches, self.device, self.depth = batches, torch.device(device), int(depth)
+        if self.device.type == 'cuda' and self.device.index is None:          # 'cuda' -> the current device, with its index
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        self.wire = torch.bfloat16 if wire_dtype == 'bf16' else None
+        self._cuda = self.device.type == 'cuda'
         self._stream = torch.cuda.Stream(device=self.device) if self._cuda else None
         self._ring = [dict() for _ in range(self.depth + 1)]      # slot -> {field: pinned staging tensor}
         self._slot_done = [None] * (self.depth + 1)               # slot -> event of the last copy that read its staging buffers
