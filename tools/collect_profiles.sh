@@ -1,14 +1,14 @@
 #!/bin/bash
 # Collect the round's measurement artifacts on the GPU box (run through gpurun from the repo root):
-#   bash tools/collect_profiles.sh r02_v1
+#   bash tools/collect_profiles.sh r03_v1
 # writes everything under gpurun_out/<tag>/; tools/publish_profiles.py copies the summaries into profiles/.
 # rocprofv3 gets the program itself after "--" (python3 bench.py ...), counters in their own passes (no trace domains with --pmc).
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-B="--no-cpu-baseline"
+B="--no-cpu-baseline --no-other-configs"
 echo "[1] default bench line (with cpu_baseline and sustained leg)"
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 echo "[2] kernel trace + stats of the same command (no cpu baseline)"
@@ -27,6 +27,11 @@ python3 bench.py --arch latefusion --seq 512 --steps 10 --warmup 3 $B --sustaine
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_latefusion512 -o tr -- python3 bench.py --arch latefusion --seq 512 --steps 10 --warmup 3 $B --sustained-steps 0 > /dev/null 2> $OUT/trace_lf.err || exit 1
 echo "[6] inference latency lines"
 for a in transformer bilstm bilstm_crf latefusion; do python3 bench.py --infer --arch $a --docs 1 --seq 2437 --steps 50 --warmup 5 2> /dev/null; done > $OUT/infer_latency.jsonl
+echo "[6b] the N > 1 step path on one GPU: one-rank RCCL group, overlapped exchange forced on"
+MTS_BENCH_SINGLE_RANK_DP=1 python3 bench.py $B --sustained-steps 200 > $OUT/bench_dp1.json 2> /dev/null
+MTS_BENCH_SINGLE_RANK_DP=1 python3 bench.py --arch latefusion --seq 512 --steps 10 --warmup 3 $B --sustained-steps 100 > $OUT/bench_dp1_latefusion512.json 2> /dev/null
+echo "[6c] host batches in the loop (PCIe-inclusive variant lines)"
+for m in "pinned fp32" "pageable fp32" "pinned bf16"; do set -- $m; python3 bench.py --h2d $1 --h2d-wire $2 $B 2> /dev/null; done > $OUT/h2d.jsonl
 echo "[7] fp32 (parity) mode throughput"
 python3 bench.py --dtype fp32 --steps 5 --warmup 2 $B --sustained-steps 0 > $OUT/bench_fp32.json 2> /dev/null
 python3 bench.py --dtype fp32 --arch bilstm --steps 5 --warmup 2 $B --sustained-steps 0 > $OUT/bench_fp32_bilstm.json 2> /dev/null

@@ -33,11 +33,14 @@ for a in ('bilstm', 'bilstm_crf', 'latefusion512'):
 cp(os.path.join(src, 'infer_latency.jsonl'), f'{tag}_infer_latency.jsonl')
 cp(os.path.join(src, 'bench_fp32.json'), f'{tag}_fp32_bench.json')
 cp(os.path.join(src, 'bench_fp32_bilstm.json'), f'{tag}_fp32_bilstm_bench.json')
-# HBM-side traffic per kernel (stamped with the kernel-source hash; bench.py reads r02_pmc_traffic.json)
+for f, n in (('bench_dp1.json', 'dp1_bench.json'), ('bench_dp1_latefusion512.json', 'dp1_latefusion512_bench.json'), ('h2d.jsonl', 'h2d.jsonl')):
+    if os.path.exists(os.path.join(src, f)):
+        cp(os.path.join(src, f), f'{tag}_{n}')
+# HBM-side traffic per kernel (stamped with the kernel-source hash; bench.py reads r03_pmc_traffic.json)
 out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'pmc_traffic.py'), one('pmc_fetch/**/*counter_collection.csv'),
-                      one('pmc_write/**/*counter_collection.csv'), os.path.join(dst, 'r02_pmc_traffic.json')], capture_output=True, text=True, check=True)
+                      one('pmc_write/**/*counter_collection.csv'), os.path.join(dst, 'r03_pmc_traffic.json')], capture_output=True, text=True, check=True)
 open(os.path.join(dst, f'{tag}_pmc_traffic.txt'), 'w').write(out.stdout)
-print(f'profiles/r02_pmc_traffic.json, profiles/{tag}_pmc_traffic.txt')
+print(f'profiles/r03_pmc_traffic.json, profiles/{tag}_pmc_traffic.txt')
 out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'pmc_summary.py'), one('pmc_sq/**/*counter_collection.csv')], capture_output=True, text=True, check=True)
 open(os.path.join(dst, f'{tag}_pmc_sq_counters.txt'), 'w').write(out.stdout)
 print(f'profiles/{tag}_pmc_sq_counters.txt')
