@@ -15,6 +15,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')    # before HIP initialises: see multimodaltopicsegmentation_amd/_lib.py (two-stream late fusion next to RCCL)
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -6,6 +6,12 @@ module raises -- build it with ``python multimodaltopicsegmentation_amd/build.py
 import ctypes as C
 import os
 
+# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The late-fusion tagger runs its two encoders on two streams;
+# once RCCL's own streams exist in the process (any N > 1 run) two of ours share a hardware queue and the encoders run one after
+# the other: 13.3 ms per step instead of 7.7 at 64 x 512 (measured with a one-rank RCCL group, profiles/r03_hw_queues.txt).
+# Eight queues restore the overlap.  Only effective if set before the HIP runtime initialises, hence here, at import.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
