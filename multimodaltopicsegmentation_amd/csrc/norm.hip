@@ -549,22 +549,25 @@ __global__ __launch_bounds__(256) void ln_head_final_kernel(const float* __restr
   }
 }
 
-// Final step of the EMB form: dpos[i][e] = sum_chunks part[chunk][i][e] for every position, and dtype0[e] = sum_i dpos[i][e] (the
-// token-type row = the sum of the pre-LN gradient over all rows), both in a fixed order.  Workgroup = 32 columns x 32 row-groups.
+// Final step of the EMB form: dpos[i][e] = sum_chunks part[chunk][i][e] for every position, in a fixed order, and the column sums
+// of the workgroup's positions -> tpart[blockIdx.y][e] (their sum over y is the token-type row = the pre-LN gradient summed over all
+// rows; slab_reduce_kernel adds them).  Workgroup = 32 columns x 32 row-groups over L / gridDim.y positions.
+#define POS_SPLIT 8
 __global__ __launch_bounds__(256) void pos_sum_kernel(const float* __restrict__ part, int nchunks, int L, int D, float* __restrict__ dpos_rows,
-                                                      float* __restrict__ dtype0) {
+                                                      float* __restrict__ tpart) {
   __shared__ float4 red[32][8];
   const int c4 = threadIdx.x & 7, grp = threadIdx.x >> 3;
   const int e = blockIdx.x * 32 + 4 * c4;
+  const int per = (L + gridDim.y - 1) / gridDim.y, i0 = blockIdx.y * per, i1 = min(L, i0 + per);
   float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e < D) {
-    for (int i = grp; i < L; i += 32) {
+    for (int i = i0 + grp; i < i1; i += 32) {
       float4 s = *reinterpret_cast<const float4*>(part + (size_t)i * D + e);
       for (int c = 1; c < nchunks; ++c) {
         const float4 v = *reinterpret_cast<const float4*>(part + ((size_t)c * L + i) * D + e);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       }
-      if (nchunks > 1 || part != dpos_rows) *reinterpret_cast<float4*>(dpos_rows + (size_t)i * D + e) = s;
+      *reinterpret_cast<float4*>(dpos_rows + (size_t)i * D + e) = s;
       tot.x += s.x; tot.y += s.y; tot.z += s.z; tot.w += s.w;
     }
   }
@@ -573,7 +576,7 @@ __global__ __launch_bounds__(256) void pos_sum_kernel(const float* __restrict__ 
   if (grp == 0 && e < D) {
     float4 t = red[0][c4];
     for (int gi = 1; gi < 32; ++gi) { const float4 v = red[gi][c4]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
-    *reinterpret_cast<float4*>(dtype0 + e) = t;
+    *reinterpret_cast<float4*>(tpart + (size_t)blockIdx.y * D + e) = t;
   }
 }
 
@@ -665,14 +668,18 @@ __global__ __launch_bounds__(64 * ROW_WAVES) void head_bwd_params_kernel(const T
 // lane streams 16-byte loads with up to 8 in flight, then the 32 groups are combined through LDS in a fixed order
 // (bitwise reproducible).  D must be a multiple of 4 (the row kernels above require it already).
 #define SR_COLS 32
-struct SlabOuts { float* o[6]; int short_slot, short_len; };   // one output row per slot (NULL: skipped); slot `short_slot` has only short_len entries
+// one output row per slot (NULL: skipped); slot `short_slot` has only short_len entries; slot `alt_slot` (if >= 0) is reduced from
+// another buffer, alt[alt_nb][D] (one row per partial)
+struct SlabOuts { float* o[6]; int short_slot, short_len; const float* alt; int alt_slot, alt_nb; };
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ partial, int nblocks, int nslots, int D, const SlabOuts so) {
+  // (partial / nblocks / nslots are re-pointed below for the slot that lives in another buffer)
   __shared__ float4 red[32][8];
   const int c4 = threadIdx.x & 7, grp = threadIdx.x >> 3;
   const int e = blockIdx.x * SR_COLS + 4 * c4;
   const int slot = blockIdx.y;
   float* o = so.o[slot];
   if (!o) return;
+  if (slot == so.alt_slot) { partial = so.alt - (size_t)slot * D; nblocks = so.alt_nb; nslots = 1; }
   const int len = (slot == so.short_slot) ? so.short_len : D;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e < len) {
@@ -704,7 +711,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 
 // used by band_attn.hip for the fused q/k/v bias gradient
 int mts_slab_reduce_rows(hipStream_t st, const float* partial, int nblocks, int D, float* out) {
-  SlabOuts so = {{out, nullptr, nullptr, nullptr, nullptr, nullptr}, -1, 0};
+  SlabOuts so = {{out, nullptr, nullptr, nullptr, nullptr, nullptr}, -1, 0, nullptr, -1, 0};
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(D, SR_COLS), 1), dim3(256), 0, st, partial, nblocks, 1, D, so);
   MTS_LAUNCH_CHECK("slab_reduce");
   return MTS_OK;
@@ -893,7 +900,7 @@ static int ln_bwd_launch(hipStream_t st, int rows, int D, const void* x, const v
     hipLaunchKernelGGL(ln_head_final_kernel<2>, dim3(ceil_div(D, 32)), dim3(256), 0, st, (const float*)partial, blocks, D, head_w, gamma, beta, dgamma,
                        dbeta, dxsum, dhead_w, dhead_b);
   else {
-    SlabOuts so = {{dgamma, dbeta, dxsum, nullptr, nullptr, nullptr}, -1, 0};
+    SlabOuts so = {{dgamma, dbeta, dxsum, nullptr, nullptr, nullptr}, -1, 0, nullptr, -1, 0};
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(D, SR_COLS), 3), dim3(256), 0, st, (const float*)partial, blocks, 3, D, so);
   }
   MTS_LAUNCH_CHECK("layernorm_bwd");
@@ -919,7 +926,7 @@ extern "C" int mts_layernorm_bwd(void* stream, int dtype, int rows, int D, const
 // ---- backward of the embedding block in one pass: LayerNorm backward + position / token-type gradient ------------------------------
 static inline int emb_chunks(int B, int L) { return std::max(1, std::min(B, ceil_div(4 * BWD_MAX_BLOCKS, L))); }
 extern "C" size_t mts_embed_layernorm_bwd_workspace(int B, int L, int D) {
-  return ((size_t)BWD_MAX_BLOCKS * 2 + (size_t)emb_chunks(B, L) * L) * (size_t)D * sizeof(float);
+  return ((size_t)BWD_MAX_BLOCKS * 2 + POS_SPLIT + (size_t)emb_chunks(B, L) * L) * (size_t)D * sizeof(float);
 }
 
 template <typename T>
@@ -933,7 +940,8 @@ static int emb_bwd_launch(hipStream_t st, int B, int L, int D, const void* pre, 
   const int ntasks = L * nchunks;
   const int blocks = std::min(BWD_MAX_BLOCKS, ceil_div(ntasks, ROW_WAVES));
   float* slabs = ws;
-  float* part = ws + (size_t)BWD_MAX_BLOCKS * 2 * D;
+  float* tpart = ws + (size_t)BWD_MAX_BLOCKS * 2 * D;               // [POS_SPLIT][D] partial token-type sums
+  float* part = tpart + (size_t)POS_SPLIT * D;
   float* out_rows = dpos + (size_t)pos_offset * D;
   EmbArgs ea = {B, L, Bc, nchunks, row0, lengths, part};
   if (row0) {                        // ragged documents: a (position, chunk) no document reaches is not written by the kernel
@@ -949,9 +957,10 @@ static int emb_bwd_launch(hipStream_t st, int B, int L, int D, const void* pre, 
       hipLaunchKernelGGL((ln_bwd_kernel<T, NV, false, false, 0, true>), dim3(blocks), dim3(64 * ROW_WAVES), 0, st, (const T*)pre, (const T*)dh,
                          (const float*)nullptr, (const float*)nullptr, 0, gamma, mean, rstd, n_rows, D, (T*)nullptr, slabs, ea);
   });
-  SlabOuts so = {{dgamma, dbeta, nullptr, nullptr, nullptr, nullptr}, -1, 0};
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(D, SR_COLS), 2), dim3(256), 0, st, (const float*)slabs, blocks, 2, D, so);
-  hipLaunchKernelGGL(pos_sum_kernel, dim3(ceil_div(D, 32)), dim3(256), 0, st, (const float*)part, nchunks, L, D, out_rows, dtype0);
+  const int ysplit = std::max(1, std::min(POS_SPLIT, L / 32));
+  hipLaunchKernelGGL(pos_sum_kernel, dim3(ceil_div(D, 32), ysplit), dim3(256), 0, st, (const float*)part, nchunks, L, D, out_rows, tpart);
+  SlabOuts so = {{dgamma, dbeta, dtype0, nullptr, nullptr, nullptr}, -1, 0, tpart, 2, ysplit};
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(D, SR_COLS), 3), dim3(256), 0, st, (const float*)slabs, blocks, 2, D, so);
   MTS_LAUNCH_CHECK("embed_layernorm_bwd");
   return MTS_OK;
 }
@@ -1029,7 +1038,7 @@ extern "C" int mts_head_bwd_params(void* stream, int dtype, int rows, int D, int
   } else { mts_set_error("mts_head_bwd_params: bad dtype %d", dtype); return MTS_ERR_INVALID; }
   float* rowp[4] = {nullptr, nullptr, nullptr, nullptr};
   for (int c = 0; c < n_out; ++c) rowp[c] = dw + (size_t)c * D;
-  SlabOuts so = {{rowp[0], rowp[1], rowp[2], rowp[3], db, nullptr}, 4, n_out};
+  SlabOuts so = {{rowp[0], rowp[1], rowp[2], rowp[3], db, nullptr}, 4, n_out, nullptr, -1, 0};
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(D, SR_COLS), 5), dim3(256), 0, st, (const float*)partial, blocks, 5, D, so);
   MTS_LAUNCH_CHECK("mts_head_bwd_params");
   return MTS_OK;
