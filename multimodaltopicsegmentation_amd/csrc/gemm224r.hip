@@ -37,6 +37,14 @@
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
+__device__ __forceinline__ bool r_shape_ok(const GemmArgs& a) {
+  const unsigned simple = MTS_EPI_BIAS | MTS_EPI_COLSCALE | MTS_EPI_RESIDUAL;
+  return !a.slab && (a.epi & ~simple) == 0 && (a.M % 256 == 0) && (a.N % R_BN == 0) && (a.K % BK == 0) && a.ksplit == a.K && (a.ldc % 8 == 0) &&
+         (((uintptr_t)a.C & 15) == 0) && (!(a.epi & MTS_EPI_COLSCALE) || a.ncols_scaled % 4 == 0) &&
+         (!(a.epi & MTS_EPI_RESIDUAL) || (a.ldr % 4 == 0 && ((uintptr_t)a.residual & 7) == 0)) &&
+         (!(a.epi & MTS_EPI_BIAS) || ((uintptr_t)a.bias & 15) == 0);
+}
+
 // (free function templates, not generic lambdas: clang rejects inline-asm operands that name variables captured by a generic lambda)
 template <bool B_KMAJOR, int I0, int N, int NGB>
 __device__ __forceinline__ void r_lds_write(unsigned sb, unsigned wA, const unsigned (&wB)[B_KMAJOR ? 1 : 4], const u32x4 (&ga)[8], const u32x4 (&gb)[NGB]) {
