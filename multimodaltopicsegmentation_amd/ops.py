@@ -60,6 +60,21 @@ def _scratch(nbytes, device, tag):
     return buf
 
 
+_side_streams = {}
+
+
+def side_stream(device, idx=0):
+    """One of a SMALL fixed pool of side HIP streams per device, shared by every model of the process.  HIP maps streams onto a
+    handful of hardware queues (GPU_MAX_HW_QUEUES, 8 here) in creation order: a process that builds several taggers, each with
+    side streams of its own, ends up with two streams that should overlap on one queue (the late-fusion line of bench.py's
+    other_configs ran 8.5 ms in such a process against 7.6 alone)."""
+    key = (str(torch.device(device)), int(idx))
+    s = _side_streams.get(key)
+    if s is None:
+        s = _side_streams[key] = torch.cuda.Stream(device=device)
+    return s
+
+
 _plan_cache = {}
 
 

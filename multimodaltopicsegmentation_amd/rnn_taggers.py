@@ -107,10 +107,7 @@ class _RnnStack:
                              # backward recurrence (which occupies 32 of the 256 CUs and is pure dependent-step latency)
 
     def _wg_stream(self, dev):
-        s = getattr(self, '_wgs', None)
-        if s is None or s.device != dev:
-            s = self._wgs = torch.cuda.Stream(device=dev)
-        return s
+        return ops.side_stream(dev, 2 if self.tag == 'r2' else 1)       # (late fusion: one per encoder; pool stream 0 is the second encoder's)
 
     def backward(self, saved, dout, lengths_i32, B, Lq):
         o, H = self.o, self.H
@@ -324,10 +321,7 @@ class BiLSTMLateFusion(_RnnTaggerBase):
                                      # order of the announcements -- model2's layers, then model1's -- is the same on every rank
 
     def _side_stream(self, dev):
-        s = getattr(self, '_enc_stream', None)
-        if s is None or s.device != dev:
-            s = self._enc_stream = torch.cuda.Stream(device=dev)
-        return s
+        return ops.side_stream(dev, 0)
 
     def __init__(self, tagset_size, embedding_dim, hidden_dim, num_layers=1, bidirectional=True, dropout_in=0.0, dropout_out=0.0,
                  batch_first=True, LSTM=True, loss_fn='CrossEntropy', threshold=None, device=None, alpha=0.9, gamma=2,

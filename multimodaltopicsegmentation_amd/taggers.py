@@ -628,10 +628,7 @@ class Transformer_segmenter(_TaggerBase):
                              # other, so per-kernel timings (bench.py's roofline) stop describing a kernel; off by default
 
     def _side_stream(self, dev):
-        s = getattr(self, '_wg_stream', None)
-        if s is None or s.device != dev:
-            s = self._wg_stream = torch.cuda.Stream(device=dev)
-        return s
+        return ops.side_stream(dev, 0)
 
     # ---- packed batches ---------------------------------------------------------------------------------
     pack_rows = 'auto'     # training path: 'auto' packs when >= 10 % of the B*L rows are padding; True / False force it
