@@ -161,6 +161,7 @@ def other_configs(device, steps=20, warmup=5):
         ('configs[2] BiLSTM 2x256 focal, 64x256x1792, bf16', lambda: BiLSTM(2, 1792, 256, num_layers=2, loss_fn='FocalLoss', compute_dtype='bf16', seed=1234), 256, 1792, None, 34.61),
         ('configs[2] BiLSTM 2x256 + CRF NLL, 64x256x1792, bf16', lambda: BiRnnCrf(2, 1792, 256, num_layers=2, compute_dtype='bf16', seed=1234), 256, 1792, None, 34.62),
         ('configs[4] per-GPU workload: late fusion 1024+768, 64x512, bf16', lambda: BiLSTMLateFusion(2, [1024, 768], 256, num_layers=2, loss_fn='FocalLoss', compute_dtype='bf16', seed=1234), 512, 1024, 768, 47.19),
+        ('configs[2] BiLSTM 2x256 focal in fp32 parity mode (the drop-in classes\' default dtype)', lambda: BiLSTM(2, 1792, 256, num_layers=2, loss_fn='FocalLoss', compute_dtype='fp32', seed=1234), 256, 1792, None, 34.61),
         ('configs[1] in fp32 parity mode (the drop-in classes\' default dtype)', lambda: Transformer_segmenter(2, 1792, 256, num_layers=1, nheads=8, loss_fn='FocalLoss', window_size=30, compute_dtype='fp32', seed=1234), 256, 1792, None, fwd_bwd_mflop_per_sentence(1792, 256, 15, 1)),
     ]
     out = {}
@@ -445,7 +446,7 @@ def main():
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'{cfg_label}: {wl}, {args.docs} docs x {args.seq} sentences per GPU, '
                                    f'fwd+bwd+Adam(eps 1e-7), inputs resident in HBM' + (', ragged lengths U{L/4..L}' + (' (padded rows kept)' if args.no_pack else ' (packed)') if args.ragged else ''),
-                       'global_batch_docs': world * args.docs, 'sentences_per_doc': args.seq, 'parallelism': f'dp{world} (document-sharded, ' + ('gloo all-reduce, every rank on cuda:0: REHEARSAL, numbers mean nothing)' if rehearsal else 'RCCL all-reduce)')},
+                       'global_batch_docs': world * args.docs, 'sentences_per_doc': args.seq, 'parallelism': f'dp{world} (document-sharded, ' + ('gloo ' if rehearsal else 'RCCL ') + ('reduce-scatter + all-gather' if trainer.exchange_schedule == 'rs_ag' else 'all-reduce') + (', every rank on cuda:0: REHEARSAL, numbers mean nothing)' if rehearsal else ')')},
             'final_loss': loss_val,
         }
         if sustained is not None:

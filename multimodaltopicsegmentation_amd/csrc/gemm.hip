@@ -403,6 +403,9 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs a, co
   const float* __restrict__ B = reinterpret_cast<const float*>(a.B);
   // operand X (rows r of the tile, k): element (r, k) at X[(r0 + r) * sr + (k0 + k) * sk]; one of sr / sk is 1
   const bool a_kc = (s.sak == 1), b_kc = (s.sbk == 1);
+  // split-K (weight gradients: few output tiles, K = all tokens): slice blockIdx.z covers [kbeg, kend) and writes its partial
+  // tile to a.slab; splitk_reduce_kernel adds the slices in a fixed order
+  const int kbeg = blockIdx.z * a.ksplit, kend = min(a.K, kbeg + a.ksplit);
   const bool a_vec = (((uintptr_t)A & 15) == 0) && ((a_kc ? s.sam : s.sak) % 4 == 0);
   const bool b_vec = (((uintptr_t)B & 15) == 0) && ((b_kc ? s.sbn : s.sbk) % 4 == 0);
   float4 ra[2], rb[2];
@@ -418,12 +421,12 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs a, co
         const int row = r0 + (f >> 2), k = k0 + (f & 3) * 4;
         if (row < rdim) {
           const float* p = X + (long)row * sr + k;
-          if (vec && k + 3 < a.K) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-          else for (int j = 0; j < 4; ++j) if (k + j < a.K) v[j] = p[j];
+          if (vec && k + 3 < kend) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+          else for (int j = 0; j < 4; ++j) if (k + j < kend) v[j] = p[j];
         }
       } else {
         const int k = k0 + (f >> 5), row = r0 + (f & 31) * 4;
-        if (k < a.K) {
+        if (k < kend) {
           const float* p = X + (long)k * sk + row;
           if (vec && row + 3 < rdim) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
           else for (int j = 0; j < 4; ++j) if (row + j < rdim) v[j] = p[j];
@@ -451,17 +454,17 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs a, co
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (a.K + F32_BK - 1) / F32_BK;
-  load_op(A, s.sam, s.sak, a_kc, a_vec, bm0, a.M, 0, ra);
-  load_op(B, s.sbn, s.sbk, b_kc, b_vec, bn0, a.N, 0, rb);
+  const int nk = (kend - kbeg + F32_BK - 1) / F32_BK;
+  load_op(A, s.sam, s.sak, a_kc, a_vec, bm0, a.M, kbeg, ra);
+  load_op(B, s.sbn, s.sbk, b_kc, b_vec, bn0, a.N, kbeg, rb);
   store_op(As[0], a_kc, ra);
   store_op(Bs[0], b_kc, rb);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) {                                  // the next K-tile's global loads fly under this tile's MFMAs
-      load_op(A, s.sam, s.sak, a_kc, a_vec, bm0, a.M, (kt + 1) * F32_BK, ra);
-      load_op(B, s.sbn, s.sbk, b_kc, b_vec, bn0, a.N, (kt + 1) * F32_BK, rb);
+      load_op(A, s.sam, s.sak, a_kc, a_vec, bm0, a.M, kbeg + (kt + 1) * F32_BK, ra);
+      load_op(B, s.sbn, s.sbk, b_kc, b_vec, bn0, a.N, kbeg + (kt + 1) * F32_BK, rb);
     }
 #pragma unroll
     for (int ks = 0; ks < F32_BK / 4; ++ks) {
@@ -824,8 +827,27 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
     MTS_CHECK_ARG(ldc % 4 == 0 && ((uintptr_t)C % 16) == 0, "mts_gemm(f32): C must be 16-byte aligned with ldc %% 4 == 0");
     MTS_CHECK_ARG(!(epilogue & MTS_EPI_RESIDUAL) || (ldr % 4 == 0), "mts_gemm(f32): ldr %% 4");
     // "gemm_f32_mfma" = 1 (default): exact-fp32 matrix-core kernel; 0: the VALU kernel (A/B, and the form the round-1 fixtures ran on)
-    if (g_f32_mfma) hipLaunchKernelGGL(gemm_f32_mfma_kernel, dim3(ceil_div(M, F32_BM) * ceil_div(N, F32_BM)), dim3(256), 0, st, a, s);
+    // split-K for the weight-gradient shapes (K = all tokens, a handful of 128 x 128 output tiles: dW_hh of one LSTM direction is 16
+    // tiles on 256 CUs): up to 16 slices of >= 512 k each while the launch stays within one wave of workgroups; plain or
+    // accumulating epilogue only (bias / residual / activation belong to the first slice and forward GEMMs have tiles enough)
+    const int nt = ceil_div(M, F32_BM) * ceil_div(N, F32_BM);
+    int splits = 1;
+    if (g_f32_mfma && workspace && !(epilogue & ~MTS_EPI_ACCUM) && N % 4 == 0 && nt <= 128 && K >= 1024) {
+      splits = std::min(std::min(16, 256 / nt), K / 512);
+      while (splits > 1 && (size_t)splits * M * N * sizeof(float) > workspace_bytes) --splits;
+    }
+    g_last_tile = 128;
+    g_last_splits = splits;
+    if (splits > 1) {
+      a.ksplit = ceil_div(ceil_div(K, splits), F32_BK) * F32_BK;
+      splits = ceil_div(K, a.ksplit);
+      a.slab = (float*)workspace;
+    }
+    if (g_f32_mfma) hipLaunchKernelGGL(gemm_f32_mfma_kernel, dim3(nt, 1, splits), dim3(256), 0, st, a, s);
     else hipLaunchKernelGGL(gemm_f32_kernel, dim3(ceil_div(M, 64) * ceil_div(N, 64)), dim3(256), 0, st, a, s);
+    if (splits > 1)
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((size_t)M * (N / 4) + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
+                         splits, M, N, (float*)C, ldc, (epilogue & MTS_EPI_ACCUM) ? 1 : 0);
     MTS_LAUNCH_CHECK("mts_gemm(f32)");
     return MTS_OK;
   }

@@ -220,6 +220,11 @@ int mts_lstm_pair_fwd(hipStream_t st, int B, int L, int H, int ndir, const void*
                       const int32_t* lengths, void* out, void* gates, float* cells, void* ws);
 int mts_lstm_pair_bwd(hipStream_t st, int B, int L, int H, int ndir, const float* w_hh, const int32_t* lengths, const void* out, const void* gates,
                       const float* cells, const void* dout, void* dxproj, void* hprev, void* ws);
+// CU-quad recurrences in fp32 (lstm_pair.hip), H = 256: parity mode
+int mts_lstm_quad_f32_fwd(hipStream_t st, int B, int L, int H, int ndir, const void* xproj, const float* w_hh, const float* b_hh,
+                          const int32_t* lengths, void* out, void* gates, float* cells, void* ws);
+int mts_lstm_quad_f32_bwd(hipStream_t st, int B, int L, int H, int ndir, const float* w_hh, const int32_t* lengths, const void* out, const void* gates,
+                          const float* cells, const void* dout, void* dxproj, void* hprev, void* ws);
 unsigned mts_lstm_pair_take_error();                  // lstm_pair.hip: sticky timeout word (pinned host memory), reading clears
 static thread_local int g_lstm_mfma = 1;
 
@@ -264,7 +269,8 @@ extern "C" int mts_lstm_fwd(void* stream, int dtype, int B, int L, int H, int nd
   if (int rc = lstm_report_async("mts_lstm_fwd")) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (g_lstm_mfma && mts_lstm_pair_supported(dtype, H))
-    return mts_lstm_pair_fwd(st, B, L, H, ndir, xproj, w_hh, b_hh, lengths, out, gates, cells, workspace);
+    return dtype == MTS_F32 ? mts_lstm_quad_f32_fwd(st, B, L, H, ndir, xproj, w_hh, b_hh, lengths, out, gates, cells, workspace)
+                            : mts_lstm_pair_fwd(st, B, L, H, ndir, xproj, w_hh, b_hh, lengths, out, gates, cells, workspace);
   if (g_lstm_mfma && mts_lstm_mfma_supported(dtype, H))
     return mts_lstm_mfma_fwd(st, B, L, H, ndir, xproj, w_hh, b_hh, lengths, out, gates, cells, workspace);
   float* whhT = (float*)workspace;
@@ -292,7 +298,8 @@ extern "C" int mts_lstm_bwd(void* stream, int dtype, int B, int L, int H, int nd
   const bool fast = g_lstm_mfma && (mts_lstm_mfma_supported(dtype, H) || mts_lstm_pair_supported(dtype, H));
   if (fast) {
     int rc = mts_lstm_pair_supported(dtype, H)
-                 ? mts_lstm_pair_bwd(st, B, L, H, ndir, w_hh, lengths, out, gates, cells, dout, dxproj, hprev, workspace)
+                 ? (dtype == MTS_F32 ? mts_lstm_quad_f32_bwd(st, B, L, H, ndir, w_hh, lengths, out, gates, cells, dout, dxproj, hprev, workspace)
+                                     : mts_lstm_pair_bwd(st, B, L, H, ndir, w_hh, lengths, out, gates, cells, dout, dxproj, hprev, workspace))
                  : mts_lstm_mfma_bwd(st, B, L, H, ndir, w_hh, lengths, out, gates, cells, dout, dxproj, hprev, workspace);
     if (rc) return rc;
   }

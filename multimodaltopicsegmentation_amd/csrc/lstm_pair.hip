@@ -353,22 +353,23 @@ unsigned mts_lstm_pair_take_error() {
   return v;
 }
 
+static thread_local int g_lstm_parts = 4;          // mts_set_option("lstm_parts", 2 | 4): CU pair or CU quad form of the recurrences
+void mts_lstm_pair_set_parts(int n) { g_lstm_parts = (n == 2) ? 2 : 4; }
 bool mts_lstm_pair_supported(int dtype, int H) {
   if (g_pair_mode < 0) { const char* e = getenv("MTS_LSTM_PAIR"); g_pair_mode = (e && e[0] == '0') ? 0 : 1; }
-  return g_pair_mode && dtype == MTS_BF16 && H == 256;
+  // fp32 (parity mode): only the CU-quad form exists (W_hh in fp32 is 256 registers per lane of a quad's waves)
+  return g_pair_mode && H == 256 && (dtype == MTS_BF16 || (dtype == MTS_F32 && g_lstm_parts == 4));
 }
 
 // workspace: packed weights (bf16) | exchange granules | status word
-static size_t pair_wbytes(int H, int ndir) { return align_up((size_t)ndir * 4 * H * H * 2, 256); }
+static size_t pair_wbytes(int H, int ndir) { return align_up((size_t)ndir * 4 * H * H * 4, 256); }     // packed W_hh: bf16 forms use half of it
 // exchange granules per (16 documents, direction): pair form 2 halves x 2 parities x 1024; quad forward 4 x 2 x 512 (the same);
-// quad backward 4 sources x 4 destinations x 2 parities x 512 -- the buffer is sized for the largest
-static size_t pair_xbytes(int B, int ndir) { return align_up((size_t)ceil_div(B, LP_DOCS * LP_GROUPS) * ndir * LP_GROUPS * 4 * 4 * 2 * 512 * sizeof(u64), 256); }
+// quad backward 4 sources x 4 destinations x 2 parities x 512 (fp32 form: 1024, one value per granule) -- sized for the largest
+static size_t pair_xbytes(int B, int ndir) { return align_up((size_t)ceil_div(B, LP_DOCS * LP_GROUPS) * ndir * LP_GROUPS * 4 * 4 * 2 * 1024 * sizeof(u64), 256); }
 // ... | status word (256 B) | dump area (stores of lanes whose document has ended)
 #define LP_DUMP_BYTES 16384
 size_t mts_lstm_pair_workspace(int B, int H, int ndir) { return pair_wbytes(H, ndir) + pair_xbytes(B, ndir) + 256 + LP_DUMP_BYTES; }
 
-static thread_local int g_lstm_parts = 4;          // mts_set_option("lstm_parts", 2 | 4): CU pair or CU quad form of the recurrences
-void mts_lstm_pair_set_parts(int n) { g_lstm_parts = (n == 2) ? 2 : 4; }
 static int lstm_quad_fwd_launch(hipStream_t st, int B, int L, int H, int ndir, const void* xproj, const bf16_t* wpk, const float* b_hh, const int32_t* lengths,
                                 void* out, void* gates, float* cells, u64* xch, unsigned* status);
 
@@ -1122,5 +1123,444 @@ int mts_lstm_pair_bwd(hipStream_t st, int B, int L, int H, int ndir, const float
                        (bf16_t*)dxproj + r0 * ndir * 4 * H, xch, status, (char*)status + 256, g_spin_limit, g_sticky_dev);
   }
   MTS_LAUNCH_CHECK("mts_lstm_bwd(pair)");
+  return MTS_OK;
+}
+
+// =====================================================================================================
+// CU-quad recurrences in FP32 (parity mode, H = 256).  The drop-in classes default to fp32; the generic fp32 recurrence
+// (lstm.hip: one workgroup per 8 documents streaming the whole W_hh through L2 in every time step) took 54 us per dependent
+// step -- 58 ms per BiLSTM training step at 64 x 256 x 1792, the paper's own configuration.  Same decomposition as the bf16
+// quad kernels above: four workgroups of 64 units per (16 documents, direction), one wave per SIMD, and W_hh in fp32 is exactly
+// 256 registers per lane of those waves (4 gate tiles x 64 k-steps of v_mfma_f32_16x16x4_f32).  h / da live in LDS in fp32 and are
+// read 16 bytes per lane: the contraction index is PERMUTED so that one ds_read_b128 feeds four k-steps (k-step 4m + j takes
+// k = 16 m + 4 g + j from lane group g; the packed weights use the same map), i.e. the sum over k is taken in a different --
+// fixed -- order than the oracle's: fp32 reassociation, ~1e-7 relative.  Exchange granules carry one fp32 each.  Transcendentals are
+// the generic kernel's (expf / tanhf), not the bf16 kernels' fast forms.
+// =====================================================================================================
+__global__ void lstm_pack_weights_f32_kernel(const float* __restrict__ w_hh, float* __restrict__ wpk, int H, int ndir, int transposed) {
+  // forward  (transposed = 0): wpk[d][p][w][gt][ks][lane] = W[gt*H + p*64 + w*16 + (lane&15)][k],  k = 16 (ks>>2) + 4 (lane>>4) + (ks&3)
+  // backward (transposed = 1): wpk[d][p][w][tt][ks][lane] = W[n][part(tt)*64 + w*16 + (lane&15)],  n = (kk/64)*H + p*64 + kk%64,
+  //                            kk = 16 (ks>>2) + 4 (lane>>4) + (ks&3),  part(0) = p, part(q+1) = (p+1+q) & 3
+  const int HQ = H / 4;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // over d, p, w, t, ks, lane
+  const size_t total = (size_t)ndir * 4 * 4 * 4 * 64 * 64;
+  if (idx >= total) return;
+  const int lane = idx % 64;
+  size_t r = idx / 64;
+  const int ks = r % 64; r /= 64;
+  const int t = r % 4; r /= 4;
+  const int w = r % 4; r /= 4;
+  const int p = r % 4; r /= 4;
+  const int d = (int)r;
+  const int kk = 16 * (ks >> 2) + 4 * (lane >> 4) + (ks & 3);
+  float v;
+  if (!transposed) {
+    const int col = t * H + p * HQ + w * 16 + (lane & 15);
+    v = w_hh[((size_t)d * 4 * H + col) * H + kk];
+  } else {
+    const int part = (t == 0) ? p : ((p + t) & 3);
+    const int j = part * HQ + w * 16 + (lane & 15);
+    const int n = (kk / HQ) * H + p * HQ + (kk % HQ);
+    v = w_hh[((size_t)d * 4 * H + n) * H + j];
+  }
+  wpk[idx] = v;
+}
+
+__global__ __launch_bounds__(256, 1) void lstm_fwd_quad_f32_kernel(int B, int L, int ndir, int nquads, const float* __restrict__ xproj,
+                                                                   const float* __restrict__ wpk, const float* __restrict__ bhh,
+                                                                   const int32_t* __restrict__ lengths, float* __restrict__ out,
+                                                                   float* __restrict__ gates, float* __restrict__ cells, u64* __restrict__ xch,
+                                                                   unsigned* __restrict__ status, char* __restrict__ dump, unsigned spin_limit,
+                                                                   unsigned* __restrict__ sticky) {
+  constexpr int H = 256, HQ = 64, NT = 256, HROW = (H + 4) * 4;      // 1040-byte rows: a 16-lane group reads 64 distinct banks
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* hbuf = smem;                                     // [parity][16][HROW] fp32
+  const int chunk = blockIdx.x / 32, within = blockIdx.x % 32;
+  const int p = within / 8, quad = chunk * 8 + within % 8;
+  if (quad >= nquads) return;
+  const int gx = quad / ndir, d = quad % ndir;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int doc = lane & 15, g4 = lane >> 4;
+  const int ul = w * 16 + 4 * g4, u = p * HQ + ul;
+  const int ldx = ndir * 4 * H, ldo = ndir * H;
+
+  float wreg[4][64];
+  {
+    const float* base = wpk + ((((size_t)d * 4 + p) * 4 + w) * 4 * 64 * 64);
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+      for (int ks = 0; ks < 64; ++ks) wreg[gt][ks] = base[(size_t)(gt * 64 + ks) * 64 + lane];
+  }
+  float bia[4][4];
+#pragma unroll
+  for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bia[gt][r] = bhh ? bhh[(size_t)d * 4 * H + gt * H + u + r] : 0.f;
+
+  const int bdoc = gx * LP_DOCS + doc;
+  const int len = (bdoc < B) ? (lengths ? min(lengths[bdoc], L) : L) : 0;
+  int maxlen = len;
+#pragma unroll
+  for (int off = 1; off < 16; off <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
+
+  // exchange areas: xch[quad][part][parity][1024 granules]; granule k2 (unit ul + k2) of (document, unit quad q = ul / 4) at k2 * 256 + q * 16 + doc
+  auto xarea = [&](int part, int par) { return xch + (((size_t)quad * 4 + part) * 2 + par) * 1024; };
+
+  float c[4] = {0.f, 0.f, 0.f, 0.f};
+  float hq[4] = {0.f, 0.f, 0.f, 0.f};
+  float4 xb[2][4];
+  for (int i = tid; i < 2 * LP_DOCS * HROW / 16; i += NT) reinterpret_cast<uint4*>(hbuf)[i] = make_uint4(0, 0, 0, 0);
+
+  const size_t b0 = (size_t)min(bdoc, B - 1) * L;
+  const size_t grow0 = b0 * ldx + (size_t)d * 4 * H + u, orow0 = b0 * ldo + (size_t)d * H + u;
+  const float* xbase = xproj + grow0;
+  auto load_x = [&](auto parc, int s) {                  // unconditional, clamped (see the bf16 kernels)
+    constexpr int PAR = decltype(parc)::value;
+    const int t = (d == 0) ? s : (len - 1 - s);
+    const float* src = xbase + (size_t)min(max(t, 0), L - 1) * ldx;
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt) xb[PAR][gt] = *reinterpret_cast<const float4*>(src + gt * H);
+  };
+  bool dead = false;
+  u64 v[3][4];
+  auto fetch_issue = [&](int s) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const u64* src = xarea((p + 1 + q) & 3, (s + 1) & 1) + tid;
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) v[q][k2] = __hip_atomic_load(src + 256 * k2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  auto fetch = [&](int s) {
+    const unsigned epoch = (unsigned)(s + 1);
+    auto tags_ok = [&]() {
+      bool ok = true;
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) ok &= ((unsigned)(v[q][k2] >> 32) == epoch);
+      return __all(ok);
+    };
+    if (!tags_ok() && !dead) {
+      unsigned spins = 0;
+#pragma clang loop unroll(disable)
+      for (;;) {
+        asm volatile("" : "+s"(spins));
+        if (++spins > spin_limit) { dead = true; if (lane == 0) lp_report_timeout(status, sticky, 1u); break; }
+        __builtin_amdgcn_s_sleep(1);
+        fetch_issue(s);
+        if (tags_ok()) break;
+      }
+    }
+    char* dst = hbuf + (((s + 1) & 1) * LP_DOCS) * HROW;
+    const int qd = tid >> 4, dd = tid & 15;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int part = (p + 1 + q) & 3;
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) *reinterpret_cast<unsigned*>(dst + dd * HROW + (part * HQ + qd * 4 + k2) * 4) = (unsigned)v[q][k2];
+    }
+  };
+
+  load_x(std::integral_constant<int, 0>{}, 0);
+  load_x(std::integral_constant<int, 1>{}, 1);
+  __syncthreads();
+
+  auto step = [&](auto parc, int s) {
+    constexpr int PAR = decltype(parc)::value;
+    const char* hcur = hbuf + (PAR * LP_DOCS) * HROW;
+    char* hnext = hbuf + ((PAR ^ 1) * LP_DOCS) * HROW;
+    f32x4 acc[4];
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt) acc[gt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const float4 hf = *reinterpret_cast<const float4*>(hcur + doc * HROW + (16 * m + 4 * g4) * 4);
+      const float hv[4] = {hf.x, hf.y, hf.z, hf.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt) acc[gt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[gt][4 * m + j], hv[j], acc[gt], 0, 0, 0);
+    }
+    const bool active = s < len;
+    float gi[4], gf[4], gg[4], go[4];
+    {
+      const float xi[4] = {xb[PAR][0].x, xb[PAR][0].y, xb[PAR][0].z, xb[PAR][0].w}, xf[4] = {xb[PAR][1].x, xb[PAR][1].y, xb[PAR][1].z, xb[PAR][1].w};
+      const float xg[4] = {xb[PAR][2].x, xb[PAR][2].y, xb[PAR][2].z, xb[PAR][2].w}, xo[4] = {xb[PAR][3].x, xb[PAR][3].y, xb[PAR][3].z, xb[PAR][3].w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        gi[r] = sigmoid_f((xi[r] + bia[0][r]) + acc[0][r]);
+        gf[r] = sigmoid_f((xf[r] + bia[1][r]) + acc[1][r]);
+        gg[r] = tanhf((xg[r] + bia[2][r]) + acc[2][r]);
+        go[r] = sigmoid_f((xo[r] + bia[3][r]) + acc[3][r]);
+        const float cn = gf[r] * c[r] + gi[r] * gg[r];
+        const float hn = go[r] * tanhf(cn);
+        c[r] = active ? cn : c[r];
+        hq[r] = active ? hn : hq[r];
+      }
+    }
+    *reinterpret_cast<float4*>(hnext + doc * HROW + u * 4) = make_float4(hq[0], hq[1], hq[2], hq[3]);
+    {
+      u64* mine = xarea(p, PAR ^ 1) + (ul >> 2) * 16 + doc;
+      const u64 tag = (u64)(unsigned)(s + 1) << 32;
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) __hip_atomic_store(mine + 256 * k2, tag | (u64)__float_as_uint(hq[k2]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    fetch_issue(s);
+    load_x(parc, s + 2);
+    fetch(s);
+    {
+      const int t = (d == 0) ? s : (len - 1 - s);
+      float* gp = active ? gates + grow0 + (size_t)t * ldx : reinterpret_cast<float*>(dump + tid * 16);
+      float* cptr = active ? cells + orow0 + (size_t)t * ldo : reinterpret_cast<float*>(dump + tid * 16);
+      float* optr = active ? out + orow0 + (size_t)t * ldo : reinterpret_cast<float*>(dump + tid * 16);
+      const int gstep = active ? H : 0;
+      *reinterpret_cast<float4*>(gp) = make_float4(gi[0], gi[1], gi[2], gi[3]);
+      *reinterpret_cast<float4*>(gp + gstep) = make_float4(gf[0], gf[1], gf[2], gf[3]);
+      *reinterpret_cast<float4*>(gp + 2 * gstep) = make_float4(gg[0], gg[1], gg[2], gg[3]);
+      *reinterpret_cast<float4*>(gp + 3 * gstep) = make_float4(go[0], go[1], go[2], go[3]);
+      *reinterpret_cast<float4*>(cptr) = make_float4(c[0], c[1], c[2], c[3]);
+      *reinterpret_cast<float4*>(optr) = make_float4(hq[0], hq[1], hq[2], hq[3]);
+    }
+    __syncthreads();
+  };
+  __builtin_amdgcn_s_waitcnt(0);
+  for (int s = 0; s < maxlen; s += 2) {
+    step(std::integral_constant<int, 0>{}, s);
+    if (s + 1 < maxlen) step(std::integral_constant<int, 1>{}, s + 1);
+  }
+  if (bdoc < B)
+    for (int t = len + g4; t < L; t += 4)
+      for (int e = 0; e < 16; e += 4) *reinterpret_cast<float4*>(out + ((size_t)bdoc * L + t) * ldo + (size_t)d * H + p * HQ + w * 16 + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+struct QuadBwdInF { float4 gi, gf, gg, go, dov, ct, cp; };
+
+__global__ __launch_bounds__(256, 1) void lstm_bwd_quad_f32_kernel(int B, int L, int ndir, int nquads, const float* __restrict__ wpkT,
+                                                                   const int32_t* __restrict__ lengths, const float* __restrict__ gates,
+                                                                   const float* __restrict__ cells, const float* __restrict__ dout,
+                                                                   float* __restrict__ dxproj, u64* __restrict__ xch, unsigned* __restrict__ status,
+                                                                   char* __restrict__ dump, unsigned spin_limit, unsigned* __restrict__ sticky) {
+  constexpr int H = 256, HQ = 64, NT = 256;
+  constexpr int DAROW = (4 * HQ + 4) * 4;                // bytes per da row (fp32)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* dabuf = smem;                                    // [2][16][DAROW]
+  const int chunk = blockIdx.x / 32, within = blockIdx.x % 32;
+  const int p = within / 8, quad = chunk * 8 + within % 8;
+  if (quad >= nquads) return;
+  const int gx = quad / ndir, d = quad % ndir;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int doc = lane & 15, g4 = lane >> 4;
+  const int ul = w * 16 + 4 * g4, u = p * HQ + ul;
+  const int ldx = ndir * 4 * H, ldo = ndir * H;
+
+  float wreg[4][64];
+  {
+    const float* base = wpkT + ((((size_t)d * 4 + p) * 4 + w) * 4 * 64 * 64);
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int ks = 0; ks < 64; ++ks) wreg[tt][ks] = base[(size_t)(tt * 64 + ks) * 64 + lane];
+  }
+  const int bdoc = gx * LP_DOCS + doc;
+  const int len = (bdoc < B) ? (lengths ? min(lengths[bdoc], L) : L) : 0;
+  int maxlen = len;
+#pragma unroll
+  for (int off = 1; off < 16; off <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
+
+  // exchange areas: xch[quad][src][dst][parity][1024 granules]; granule k2 of the position lane `tid` owns on either side at k2 * 256 + tid
+  auto xarea = [&](int src, int dst, int par) { return xch + ((((size_t)quad * 4 + src) * 4 + dst) * 2 + par) * 1024; };
+  for (int i = tid; i < 2 * LP_DOCS * DAROW / 4; i += NT) reinterpret_cast<unsigned*>(smem)[i] = 0u;
+
+  const size_t b0 = (size_t)min(bdoc, B - 1) * L;
+  const size_t grow0 = b0 * ldx + (size_t)d * 4 * H + u, orow0 = b0 * ldo + (size_t)d * H + u;
+  auto load_in = [&](int s, QuadBwdInF& in) {
+    const int sc = max(s, 0);
+    const int t = min(max((d == 0) ? sc : (len - 1 - sc), 0), L - 1);
+    const int tp = min(max((d == 0) ? t - 1 : t + 1, 0), L - 1);
+    const float* gp = gates + grow0 + (size_t)t * ldx;
+    in.gi = *reinterpret_cast<const float4*>(gp);
+    in.gf = *reinterpret_cast<const float4*>(gp + H);
+    in.gg = *reinterpret_cast<const float4*>(gp + 2 * H);
+    in.go = *reinterpret_cast<const float4*>(gp + 3 * H);
+    in.dov = *reinterpret_cast<const float4*>(dout + orow0 + (size_t)t * ldo);
+    in.ct = *reinterpret_cast<const float4*>(cells + orow0 + (size_t)t * ldo);
+    in.cp = *reinterpret_cast<const float4*>(cells + orow0 + (size_t)tp * ldo);
+  };
+  bool dead = false;
+  u64 v[3][4];
+  auto fetch_issue = [&](int s) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const u64* src = xarea((p + 1 + q) & 3, p, s & 1) + tid;
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) v[q][k2] = __hip_atomic_load(src + NT * k2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  auto fetch = [&](int s) {
+    const unsigned epoch = (unsigned)(maxlen - s);
+    auto tags_ok = [&]() {
+      bool ok = true;
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) ok &= ((unsigned)(v[q][k2] >> 32) == epoch);
+      return __all(ok);
+    };
+    if (!tags_ok() && !dead) {
+      unsigned spins = 0;
+#pragma clang loop unroll(disable)
+      for (;;) {
+        asm volatile("" : "+s"(spins));
+        if (++spins > spin_limit) { dead = true; if (lane == 0) lp_report_timeout(status, sticky, 2u); break; }
+        __builtin_amdgcn_s_sleep(1);
+        fetch_issue(s);
+        if (tags_ok()) break;
+      }
+    }
+  };
+
+  float dc[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x4 own = (f32x4){0.f, 0.f, 0.f, 0.f};
+  QuadBwdInF in[2];
+  load_in(maxlen - 1, in[0]);
+  load_in(maxlen - 2, in[1]);
+  __syncthreads();
+
+  auto step = [&](auto parc, int s) {
+    constexpr int PAR = decltype(parc)::value;
+    char* da = dabuf + PAR * LP_DOCS * DAROW;
+    const bool active = s < len;
+    const QuadBwdInF& cur = in[PAR];
+    float dhv[4] = {own[0], own[1], own[2], own[3]};
+    if (s + 1 <= maxlen - 1) {
+      fetch(s + 1);
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) dhv[k2] += __uint_as_float((unsigned)v[q][k2]);
+    }
+    float ai[4], af[4], ag[4], ao[4];
+    {
+      const float gi[4] = {cur.gi.x, cur.gi.y, cur.gi.z, cur.gi.w}, gf[4] = {cur.gf.x, cur.gf.y, cur.gf.z, cur.gf.w};
+      const float gg[4] = {cur.gg.x, cur.gg.y, cur.gg.z, cur.gg.w}, go[4] = {cur.go.x, cur.go.y, cur.go.z, cur.go.w};
+      const float dov[4] = {cur.dov.x, cur.dov.y, cur.dov.z, cur.dov.w}, ct[4] = {cur.ct.x, cur.ct.y, cur.ct.z, cur.ct.w};
+      const bool has_prev = s > 0;
+      const float cp[4] = {has_prev ? cur.cp.x : 0.f, has_prev ? cur.cp.y : 0.f, has_prev ? cur.cp.z : 0.f, has_prev ? cur.cp.w : 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float tc = tanhf(ct[r]);
+        const float dht = dov[r] + dhv[r];
+        const float dct = dc[r] + dht * go[r] * (1.f - tc * tc);
+        ai[r] = active ? dct * gg[r] * gi[r] * (1.f - gi[r]) : 0.f;
+        af[r] = active ? dct * cp[r] * gf[r] * (1.f - gf[r]) : 0.f;
+        ag[r] = active ? dct * gi[r] * (1.f - gg[r] * gg[r]) : 0.f;
+        ao[r] = active ? dht * tc * go[r] * (1.f - go[r]) : 0.f;
+        dc[r] = active ? dct * gf[r] : dc[r];
+      }
+    }
+    char* dr = da + doc * DAROW + ul * 4;
+    *reinterpret_cast<float4*>(dr) = make_float4(ai[0], ai[1], ai[2], ai[3]);
+    *reinterpret_cast<float4*>(dr + HQ * 4) = make_float4(af[0], af[1], af[2], af[3]);
+    *reinterpret_cast<float4*>(dr + 2 * HQ * 4) = make_float4(ag[0], ag[1], ag[2], ag[3]);
+    *reinterpret_cast<float4*>(dr + 3 * HQ * 4) = make_float4(ao[0], ao[1], ao[2], ao[3]);
+    load_in(s - 2, in[PAR]);
+    {
+      const int t = (d == 0) ? s : (len - 1 - s);
+      float* dx = active ? dxproj + grow0 + (size_t)t * ldx : reinterpret_cast<float*>(dump + tid * 16);
+      const int gstep = active ? H : 0;
+      *reinterpret_cast<float4*>(dx) = make_float4(ai[0], ai[1], ai[2], ai[3]);
+      *reinterpret_cast<float4*>(dx + gstep) = make_float4(af[0], af[1], af[2], af[3]);
+      *reinterpret_cast<float4*>(dx + 2 * gstep) = make_float4(ag[0], ag[1], ag[2], ag[3]);
+      *reinterpret_cast<float4*>(dx + 3 * gstep) = make_float4(ao[0], ao[1], ao[2], ao[3]);
+    }
+    __syncthreads();
+    f32x4 acc[4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const float4 bf = *reinterpret_cast<const float4*>(da + doc * DAROW + (16 * m + 4 * g4) * 4);
+      const float bv[4] = {bf.x, bf.y, bf.z, bf.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int tt = 3; tt >= 0; --tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[tt][4 * m + j], bv[j], acc[tt], 0, 0, 0);
+    }
+    {
+      const u64 tag = (u64)(unsigned)(maxlen - s) << 32;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        u64* dst = xarea(p, (p + 1 + q) & 3, s & 1) + tid;
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) __hip_atomic_store(dst + NT * k2, tag | (u64)__float_as_uint(acc[q + 1][k2]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    own = acc[0];
+    if (s - 1 >= 0) fetch_issue(s);
+  };
+  __builtin_amdgcn_s_waitcnt(0);
+  for (int s = maxlen - 1; s >= 0; s -= 2) {
+    step(std::integral_constant<int, 0>{}, s);
+    if (s - 1 >= 0) step(std::integral_constant<int, 1>{}, s - 1);
+  }
+  if (bdoc < B)
+    for (int t = len; t < L; ++t)
+#pragma unroll
+      for (int gt = 0; gt < 4; ++gt) *reinterpret_cast<float4*>(dxproj + ((size_t)bdoc * L + t) * ldx + (size_t)d * 4 * H + gt * H + u) = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+static int quad_f32_common(hipStream_t st, int B, int H, int ndir, const float* w_hh, void* ws, int transposed, float** wpk, u64** xch, unsigned** status) {
+  *wpk = (float*)ws;
+  *xch = (u64*)((char*)ws + pair_wbytes(H, ndir));
+  *status = (unsigned*)((char*)*xch + pair_xbytes(B, ndir));
+  const size_t total = (size_t)ndir * 4 * 4 * 4 * 64 * 64;
+  hipLaunchKernelGGL(lstm_pack_weights_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w_hh, *wpk, H, ndir, transposed);
+  if (hipMemsetAsync(*xch, 0, pair_xbytes(B, ndir) + 256, st) != hipSuccess) { mts_set_error("lstm_quad(f32): memset failed"); return MTS_ERR_LAUNCH; }
+  return lp_ensure_sticky();
+}
+
+int mts_lstm_quad_f32_fwd(hipStream_t st, int B, int L, int H, int ndir, const void* xproj, const float* w_hh, const float* b_hh,
+                          const int32_t* lengths, void* out, void* gates, float* cells, void* ws) {
+  float* wpk; u64* xch; unsigned* status;
+  if (int rc = quad_f32_common(st, B, H, ndir, w_hh, ws, 0, &wpk, &xch, &status)) return rc;
+  const size_t lds = (size_t)2 * LP_DOCS * (H + 4) * 4;
+  const int max_quads = std::max(1, std::min(LQ_MAX_QUADS, g_max_pairs / 2));
+  const int docs_per_launch = std::max(1, max_quads / ndir) * LP_DOCS;
+  for (int b0 = 0; b0 < B; b0 += docs_per_launch) {
+    const int bc = std::min(docs_per_launch, B - b0);
+    const size_t r0 = (size_t)b0 * L;
+    if (b0 > 0 && hipMemsetAsync(xch, 0, pair_xbytes(bc, ndir) + 256, st) != hipSuccess) { mts_set_error("lstm_quad(f32): memset failed"); return MTS_ERR_LAUNCH; }
+    const int nquads = ceil_div(bc, LP_DOCS) * ndir;
+    hipLaunchKernelGGL(lstm_fwd_quad_f32_kernel, dim3(32 * ceil_div(nquads, 8)), dim3(256), lds, st, bc, L, ndir, nquads, (const float*)xproj + r0 * ndir * 4 * H,
+                       (const float*)wpk, b_hh, lengths ? lengths + b0 : nullptr, (float*)out + r0 * ndir * H, (float*)gates + r0 * ndir * 4 * H,
+                       cells + r0 * ndir * H, xch, status, (char*)status + 256, g_spin_limit, g_sticky_dev);
+  }
+  MTS_LAUNCH_CHECK("mts_lstm_fwd(quad f32)");
+  return MTS_OK;
+}
+
+int mts_lstm_quad_f32_bwd(hipStream_t st, int B, int L, int H, int ndir, const float* w_hh, const int32_t* lengths, const void* out, const void* gates,
+                          const float* cells, const void* dout, void* dxproj, void* hprev, void* ws) {
+  float* wpk; u64* xch; unsigned* status;
+  if (int rc = quad_f32_common(st, B, H, ndir, w_hh, ws, 1, &wpk, &xch, &status)) return rc;
+  const size_t rows4 = (size_t)B * L * ndir * H / 4;
+  hipLaunchKernelGGL(lstm_hprev_kernel<float>, dim3((unsigned)((rows4 + 255) / 256)), dim3(256), 0, st, B, L, H, ndir, lengths, (const float*)out, (float*)hprev);
+  const size_t lds = (size_t)2 * LP_DOCS * (4 * (H / 4) + 4) * 4;
+  const int max_quads = std::max(1, std::min(LQ_MAX_QUADS, g_max_pairs / 2));
+  const int docs_per_launch = std::max(1, max_quads / ndir) * LP_DOCS;
+  for (int b0 = 0; b0 < B; b0 += docs_per_launch) {
+    const int bc = std::min(docs_per_launch, B - b0);
+    const size_t r0 = (size_t)b0 * L;
+    if (b0 > 0 && hipMemsetAsync(xch, 0, pair_xbytes(bc, ndir) + 256, st) != hipSuccess) { mts_set_error("lstm_quad(f32): memset failed"); return MTS_ERR_LAUNCH; }
+    const int nquads = ceil_div(bc, LP_DOCS) * ndir;
+    hipLaunchKernelGGL(lstm_bwd_quad_f32_kernel, dim3(32 * ceil_div(nquads, 8)), dim3(256), lds, st, bc, L, ndir, nquads, (const float*)wpk,
+                       lengths ? lengths + b0 : nullptr, (const float*)gates + r0 * ndir * 4 * H, cells + r0 * ndir * H, (const float*)dout + r0 * ndir * H,
+                       (float*)dxproj + r0 * ndir * 4 * H, xch, status, (char*)status + 256, g_spin_limit, g_sticky_dev);
+  }
+  MTS_LAUNCH_CHECK("mts_lstm_bwd(quad f32)");
   return MTS_OK;
 }

@@ -101,7 +101,7 @@ def gemm(layout, A, B, out, *, M, N, K, lda=None, ldb=None, ldc=None, bias=None,
     ldb = ldb if ldb is not None else B.stride(0)
     ldc = ldc if ldc is not None else out.stride(0)
     ws, ws_bytes = None, 0
-    if layout in (L.TN, L.TT) and c_dt == L.F32 and a_dt == L.BF16 and K >= 2048:
+    if layout in (L.TN, L.TT) and c_dt == L.F32 and K >= 2048:
         ws_bytes = min(16, max(1, K // 1024)) * M * N * 4          # room for up to 16 split-K partial planes
         ws = _scratch(ws_bytes, A.device, 'splitk')
     key = (layout, a_dt, c_dt, M, N, K)

@@ -10,6 +10,8 @@ This is the MI355X-first replacement for what Lightning does around ``TextSegmen
   * Adam(eps 1e-7) / SGD(momentum .9, wd 1e-4) (lightning_model.py:759-765) is one streaming kernel over the
     flat buffer that also emits the bf16 weight mirror for the next step's GEMMs.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -43,7 +45,7 @@ def local_loss_count(model, batch):
 
 class NativeTrainer:
     def __init__(self, model, lr=1e-3, optimizer='Adam', process_group=None, token_weighted=False, grad_exchange_dtype='fp32',
-                 always_hook=False):
+                 always_hook=False, exchange_schedule=None):
         """model: a tagger from taggers.py / rnn_taggers.py (or a TextSegmenter, whose .model is used).
 
         token_weighted: the reference's loss is a mean over the LOCAL batch's valid sentences (models/CRF.py:352), so plain data
@@ -54,6 +56,12 @@ class NativeTrainer:
         grad_exchange_dtype: 'fp32' | 'bf16'.  bf16 halves the bytes on the xGMI ring (84.5 -> 42.3 MB per step for the 1-layer
         band encoder); each rank's contribution is rounded to bf16 (relative 2^-9) and summed in bf16 by the collective, so the
         exchanged sum is within 2^-8 * sum_r |g_r| of the fp32 one (tests/test_distributed_cpu.py).
+
+        exchange_schedule: 'allreduce' (default) | 'rs_ag' (env MTS_DP_SCHEDULE when None).  'rs_ag' exchanges every span as a
+        reduce-scatter into 1/world shards followed by an all-gather of the reduced shards (the remainder of a span that does not
+        divide by world goes through a small all-reduce): SURVEY.md 8(e)'s schedule -- on a fully connected xGMI node each rank then
+        talks to its 7 peers at once instead of passing whole buffers round one ring.  Same sum on every rank; for world = 2 the same
+        bits as 'allreduce'.  Behind a switch until an 8-GPU node has timed the two.
 
         always_hook: take the overlapped exchange path (gradient-ready hooks -> asynchronous all-reduce per span) even in a
         process group of ONE rank.  Measurement aid: the N > 1 step path -- hook order, per-projection release, collective
@@ -73,6 +81,11 @@ class NativeTrainer:
         self.exchange_bf16 = grad_exchange_dtype == 'bf16'
         self._xbuf = None
         self.last_global_count = None
+        sched = exchange_schedule if exchange_schedule is not None else os.environ.get('MTS_DP_SCHEDULE', 'allreduce')
+        if sched not in ('allreduce', 'rs_ag'):
+            raise ValueError("exchange_schedule must be 'allreduce' or 'rs_ag'")
+        self.exchange_schedule = sched
+        self._inflight_shards = []
 
     def _state(self):
         flat = self.model.flat
@@ -121,19 +134,41 @@ class NativeTrainer:
         self.last_global_count = total
         return self.world * n_local / total if total > 0 else 1.0
 
+    def _sum_in_place(self, buf, async_op):
+        """SUM of `buf` over the ranks, in place, by the configured schedule -> list of work handles (async_op) or []."""
+        world = self.world
+        if self.exchange_schedule != 'rs_ag' or (world == 1 and not self.always_hook) or buf.numel() < world:
+            h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
+            return [h] if async_op else []
+        n = buf.numel()
+        per = n // world
+        body = per * world
+        # one shard buffer per in-flight span: the all-gather reads it after this call has returned
+        shard = torch.empty(per, dtype=buf.dtype, device=buf.device)
+        hs = [dist.reduce_scatter_tensor(shard, buf[:body], op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)]
+        if async_op and dist.get_backend(self.pg) != 'nccl':
+            hs[0].wait()          # gloo runs asynchronous work on a thread pool: the gather below must not overtake the scatter.  (RCCL
+                                  # orders the collectives of one communicator on its stream -- no host or stream wait needed there.)
+        hs.append(dist.all_gather_into_tensor(buf[:body], shard, group=self.pg, async_op=async_op))
+        if body < n:
+            hs.append(dist.all_reduce(buf[body:], op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op))
+        if async_op and shard.device.type == 'cuda':
+            self._inflight_shards.append(shard)       # keep the caching allocator from recycling it under the collectives
+        return hs if async_op else []
+
     def _exchange(self, a, b, async_op):
-        """SUM all-reduce of flat-gradient span [a, b) in the exchange dtype."""
+        """SUM of flat-gradient span [a, b) over the ranks in the exchange dtype -> (work handles, span to copy back | None)."""
         g = self.model.grad_flat()
         if not self.exchange_bf16:
-            return dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op), None
+            return self._sum_in_place(g[a:b], async_op), None
         if self._xbuf is None or self._xbuf.numel() < g.numel() or self._xbuf.device != g.device:
             self._xbuf = torch.empty(g.numel(), dtype=torch.bfloat16, device=g.device)
         buf = self._xbuf[a:b]
         buf.copy_(g[a:b])                             # fp32 -> bf16 (round to nearest even), behind the kernels that wrote the span
-        return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op), (a, b)
+        return self._sum_in_place(buf, async_op), (a, b)
 
-    def _finish(self, handle, span):
-        if handle is not None:
+    def _finish(self, handles, span):
+        for handle in handles or ():
             handle.wait()                             # stream-level wait: what follows is ordered behind the collective
         if span is not None:
             a, b = span
@@ -172,6 +207,7 @@ class NativeTrainer:
         m.loss_grad_scale = self.exchange_weight(batch)
         overlapped = (self.world > 1 or self.always_hook) and getattr(m, 'grad_hooks_cover_all', False)
         self._pending = []
+        self._inflight_shards = []
         m._grad_hook = self._on_grads_ready if overlapped else None
         if batch.get('src_tokens2') is not None and hasattr(m, '_rnn2'):
             loss, _ = m.loss_and_grad(x, batch['src_tokens2'], lengths, tags, True)
@@ -181,6 +217,7 @@ class NativeTrainer:
             for h, span in self._pending:
                 self._finish(h, span)         # stream-level wait: the optimizer kernel is ordered behind the collectives
             self._pending = []
+            self._inflight_shards = []
         else:
             self.allreduce_grads()
         self.apply_optimizer()

@@ -121,12 +121,12 @@ def _make_model(kind):
     return BiLSTM(2, D, 16, num_layers=1, loss_fn='FocalLoss', compute_dtype='fp32', seed=3), _bilstm_oracle_grads
 
 
-def _worker2(rank, world, port, out_dir, kind, token_weighted, xdtype):
+def _worker2(rank, world, port, out_dir, kind, token_weighted, xdtype, schedule='allreduce'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from multimodaltopicsegmentation_amd.trainer import NativeTrainer, shard_batch, local_loss_count
     model, oracle = _make_model(kind)
-    tr = NativeTrainer(model, lr=1e-3, token_weighted=token_weighted, grad_exchange_dtype=xdtype)
+    tr = NativeTrainer(model, lr=1e-3, token_weighted=token_weighted, grad_exchange_dtype=xdtype, exchange_schedule=schedule)
     shard = shard_batch(_make_ragged_batch(), rank, world)
     assert local_loss_count(model, shard) == sum(RAGGED[rank::world])
     w = tr.exchange_weight(shard)
@@ -203,3 +203,31 @@ def test_bf16_gradient_exchange_error_bound(tmp_path):
         checked += got.numel()
         # and the rounding is real: the bf16 result is not the fp32 sum everywhere
     assert checked > 1000
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('xdtype', ['fp32', 'bf16'])
+def test_reduce_scatter_all_gather_schedule_gives_the_all_reduce_sum(tmp_path, world, xdtype):
+    """exchange_schedule='rs_ag' (every rank reduces 1/world of each span and the reduced shards are gathered) against
+    the plain all-reduce on the same ragged shards: every rank ends with the same bits, and the sum is the all-reduce's -- bit for bit
+    at world 2 (one addition per element either way), to fp32 / bf16 rounding of a three-term sum at world 3, where the spans do
+    not divide by the world size (the remainder takes the small all-reduce)."""
+    outs = {}
+    for sched in ('allreduce', 'rs_ag'):
+        out = tmp_path / sched
+        out.mkdir()
+        mp.spawn(_worker2, args=(world, _free_port(), str(out), 'transformer', False, xdtype, sched), nprocs=world, join=True)
+        outs[sched] = [torch.load(out / f'g{r}.pt')['sum'] for r in range(world)]
+    n_odd = 0
+    for k in outs['rs_ag'][0]:
+        for r in range(1, world):
+            assert torch.equal(outs['rs_ag'][0][k], outs['rs_ag'][r][k]), (k, r)
+        a, b = outs['allreduce'][0][k], outs['rs_ag'][0][k]
+        if world == 2:
+            assert torch.equal(a, b), k
+        else:
+            tol = 1e-6 if xdtype == 'fp32' else 2 ** -7
+            assert float((a - b).abs().max()) <= tol * max(float(a.abs().max()), 1e-30), k
+        n_odd += a.numel() % world != 0
+    assert world == 2 or n_odd > 0

@@ -50,11 +50,11 @@ def test_bench_ragged_counts_valid_sentences_only():
 
 def test_default_line_witnesses_the_other_baseline_configurations():
     """the driver's BENCH record carries 20-step figures of configs[2] (focal and CRF heads), configs[4]'s per-GPU
-    workload and the fp32 parity mode under extra.other_configs; `value` / `roofline` stay on configs[1]."""
+    workload and the fp32 parity mode (transformer and BiLSTM) under extra.other_configs; `value` / `roofline` stay on configs[1]."""
     j = _run('--steps', '3', '--warmup', '2', '--cpu-docs', '1', '--sustained-steps', '0')
     assert j['config']['workload'].startswith('BASELINE configs[1]')
     oc = j['extra']['other_configs']
-    assert len(oc) == 4 and sum('configs[2]' in k for k in oc) == 2 and sum('configs[4]' in k for k in oc) == 1 and sum('fp32' in k for k in oc) == 1
+    assert len(oc) == 5 and sum('configs[2]' in k for k in oc) == 3 and sum('configs[4]' in k for k in oc) == 1 and sum('fp32' in k for k in oc) == 2
     for k, v in oc.items():
         assert v['steps'] == 20 and v['ms_per_step'] > 0 and v['final_loss'] == v['final_loss'], k
         seq = 512 if 'configs[4]' in k else 256
@@ -101,3 +101,9 @@ def test_single_rank_data_parallel_step_path_over_rccl(arch):
     assert 'one-rank RCCL group' in ja['config']['workload']
     # (not bitwise: under a hook the q/k/v weight gradient is three GEMMs with their own K splits, and bf16 weights follow)
     assert abs(ja['final_loss'] - jb['final_loss']) <= 2e-3 * max(1.0, abs(jb['final_loss'])), (ja['final_loss'], jb['final_loss'])
+    # the reduce-scatter + all-gather schedule through RCCL itself (one rank: both collectives are copies, issued back to back on
+    # RCCL's stream with no wait between them): the same loss as the all-reduce schedule, bit for bit
+    c = _run_env({'MTS_BENCH_SINGLE_RANK_DP': '1', 'MTS_DP_SCHEDULE': 'rs_ag'}, *flags)
+    assert c.returncode == 0, c.stderr[-3000:]
+    jc = json.loads([ln for ln in c.stdout.splitlines() if ln.startswith('{')][0])
+    assert 'reduce-scatter + all-gather' in jc['config']['parallelism'] and jc['final_loss'] == ja['final_loss'], (jc['final_loss'], ja['final_loss'])

@@ -74,13 +74,13 @@ def _run(kind, ragged, rank, world):
     return model.flat.detach().cpu().clone(), losses, tr
 
 
-def _worker(rank, world, port, out_dir, kind, ragged):
+def _worker(rank, world, port, out_dir, kind, ragged, schedule='allreduce'):
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), MTS_DP_SCHEDULE=schedule)
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     flat, losses, tr = _run(kind, ragged, rank, world)
-    assert tr.world == world
+    assert tr.world == world and tr.exchange_schedule == schedule
     # the overlapped path ran: hooks installed, nothing left pending
     assert getattr(tr.model, 'grad_hooks_cover_all', False) and tr._pending == [] and tr.model._grad_hook is not None
     torch.save({'flat': flat, 'losses': losses}, os.path.join(out_dir, f'r{rank}.pt'))
@@ -111,3 +111,21 @@ def test_two_rank_native_step_equals_the_single_process_step(tmp_path, kind, rag
     n = [int(b0['src_lengths'][r::world].sum()) for r in range(world)]
     w = [v / sum(n) for v in n] if ragged else [0.5, 0.5]
     assert abs(w[0] * r0['losses'][0] + w[1] * r1['losses'][0] - losses[0]) <= 2e-6 * max(1.0, abs(losses[0]))
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('kind', ['transformer', 'latefusion'])
+def test_reduce_scatter_all_gather_schedule_in_the_overlapped_step(tmp_path, kind):
+    """MTS_DP_SCHEDULE=rs_ag (trainer.NativeTrainer exchange_schedule): every span announced by the backward is reduce-scattered and
+    the reduced shards gathered, asynchronously, the optimizer ordered behind them.  At world 2 each element is one addition either way:
+    the parameters after two steps must equal the all-reduce schedule's bit for bit."""
+    import torch.multiprocessing as mp
+    world, flats = 2, {}
+    for sched in ('allreduce', 'rs_ag'):
+        out = tmp_path / sched
+        out.mkdir()
+        mp.spawn(_worker, args=(world, _free_port(), str(out), kind, False, sched), nprocs=world, join=True)
+        r0, r1 = torch.load(out / 'r0.pt'), torch.load(out / 'r1.pt')
+        assert torch.equal(r0['flat'], r1['flat'])
+        flats[sched] = r0['flat']
+    assert torch.equal(flats['allreduce'], flats['rs_ag'])

@@ -513,3 +513,42 @@ def test_gemm_f32_matrix_core_kernel_matches_the_valu_kernel(ops, layout, M, N, 
     assert float((outs[1].double() - ref).abs().max()) < 2e-6 * (K ** 0.5) * scale
     # measured on MI355X: the instruction chains its four products in k order, so the two kernels agree bit for bit
     assert torch.equal(outs[1], outs[0])
+
+
+@pytest.mark.parametrize('layout', ['TN', 'TT'])
+@pytest.mark.parametrize('M,N,K', [(1024, 256, 16384), (256, 1792, 4104), (130, 68, 3000)])
+def test_gemm_f32_split_k_weight_gradient_shapes(ops, layout, M, N, K):
+    """fp32 weight gradients have a handful of 128 x 128 output tiles and K = every token of the batch: the matrix-core fp32 kernel splits
+    K into up to 16 slices (partial tiles -> workspace, summed in slice order by splitk_reduce_kernel).  Against fp64 math, plain and
+    accumulating into a non-zero C, a ragged last slice (K not a multiple of 16 x slices), and the same bits run after run."""
+    from multimodaltopicsegmentation_amd import _lib as L
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(K, M, generator=g)
+    B = torch.randn(K, N, generator=g) if layout == 'TN' else torch.randn(N, K, generator=g)
+    ref = A.double().t() @ (B.double() if layout == 'TN' else B.double().t())
+    scale = float(ref.abs().max())
+    Ad, Bd = A.to(DEV), B.to(DEV)
+    out = torch.full((M, N), float('nan'), device=DEV)
+    ops.gemm(getattr(L, layout), Ad, Bd, out, M=M, N=N, K=K)
+    splits = ctypes_int()
+    L.lib.mts_gemm_last_plan(None, splits.ref)
+    assert splits.value > 1, splits.value
+    assert float((out.cpu().double() - ref).abs().max()) < 2e-6 * (K ** 0.5) * scale
+    acc = torch.full((M, N), 3.0, device=DEV)
+    ops.gemm(getattr(L, layout), Ad, Bd, acc, M=M, N=N, K=K, accumulate=True)
+    assert float((acc.cpu().double() - ref - 3.0).abs().max()) < 2e-6 * (K ** 0.5) * scale
+    for _ in range(3):
+        again = torch.empty(M, N, device=DEV)
+        ops.gemm(getattr(L, layout), Ad, Bd, again, M=M, N=N, K=K)
+        assert torch.equal(again, out)
+
+
+class ctypes_int:
+    def __init__(self):
+        import ctypes
+        self._c = ctypes.c_int(0)
+        self.ref = ctypes.byref(self._c)
+
+    @property
+    def value(self):
+        return self._c.value
