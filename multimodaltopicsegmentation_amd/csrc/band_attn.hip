@@ -455,8 +455,9 @@ extern "C" int mts_band_attn_bwd(void* stream, int dtype, int B, int L, int D, i
   a.q_scale = q_scale;
   if (dtype == MTS_BF16 && g_band_mfma) {
     a.bias_slab = dbias ? (float*)workspace : nullptr;      // column sums fused into the kernels' output stage
-    rc = mts_band_mfma_bwd(a, (hipStream_t)stream);
-    if (rc == MTS_OK && dbias) return mts_slab_reduce_rows((hipStream_t)stream, (const float*)workspace, B * ceil_div(L, 128), 3 * D, dbias);
+    int slab_rows = 0;
+    rc = mts_band_mfma_bwd(a, (hipStream_t)stream, &slab_rows);
+    if (rc == MTS_OK && dbias) return mts_slab_reduce_rows((hipStream_t)stream, (const float*)workspace, slab_rows, 3 * D, dbias);
     if (rc >= 0) return rc;
     a.bias_slab = nullptr;
   }

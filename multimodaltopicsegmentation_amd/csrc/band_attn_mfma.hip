@@ -446,6 +446,275 @@ __global__ __launch_bounds__(256, OCC) void band_mfma_bwd_kv_kernel(const BandAr
 }
 
 // ------------------------------------------------------------------------------------------------
+// backward in ONE pass (radius <= 15, head dim <= 224): q, k, v, dCtx and the probabilities are read once, dq, dk, dv written once,
+// dS never leaves the chip.  A 512-thread workgroup owns FROWS = 256 rows of one (document, head): every document of at most 256
+// sentences is ONE tile (no halo at all: the BASELINE shape); longer documents are cut into tiles of 192 key rows whose 224 query
+// rows include a 16-row halo on either side (key j needs the coefficients of queries j - w .. j + w, and a query's dS needs its whole
+// window, so halo queries are recomputed by both neighbours: 224 / 192 of the per-query work).
+//   part 1 (wave = 32 query rows, as band_mfma_bwd_q_kernel): dP^T = V.dCtx^T, dS = P (dP - rowsum(P dP)), dQ = q_scale dS.K from the K
+//           image; P (dropped form) and dS are left in LDS as bf16, transposed: XT[key - t0][query & 31] (a key's 2w + 1 queries are
+//           distinct modulo 32), 16 KB each;
+//   part 2 (wave = 32 key rows, as band_mfma_bwd_kv_kernel): the B operand of key j is 8 consecutive queries = ONE 16-byte LDS read of
+//           XT (the window is anchored at j0 - 16, a multiple of 8), masked to |i - j| <= w; dV = P^T.dCtx and dK = dS^T.Q from the
+//           dCtx and Q images.  The three 256-row images share one LDS region (3 x 112 KB do not fit), staged one after the other.
+// ------------------------------------------------------------------------------------------------
+#define FROWS 256
+
+template <int KK>
+__device__ __forceinline__ void stage_dma8(char* img, const bf16_t* __restrict__ doc_base, int ld, int first, int nrows, int L) {
+  constexpr int CPR = 4 * KK;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int total = nrows * CPR;                         // nrows is a multiple of 16: whole 64-chunk pieces
+  for (int base = wave * 64; base < total; base += 512) {
+    const int idx = base + lane;
+    const int r = idx / CPR, ch = idx - r * CPR;
+    const int j = min(max(first + r, 0), L - 1);
+    const bf16_t* src = doc_base + (size_t)j * ld + ch * 8;
+    __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(img + base * 16), 16, 0, 0);
+  }
+}
+
+// cv_phase with the image rows given per lane (already including the lane's row-in-quad and clamped into the staged rows)
+template <int KK, int NS>
+__device__ __forceinline__ void cv_phase_rows(const char* img, const int (&rlo)[NS], const int (&rhi)[NS], const bf16x8 (&coef)[NS][2], int lane,
+                                              f32x4 (&o)[2 * KK][2]) {
+  constexpr int RS = 64 * KK;
+  const int p = lane & 3;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const char* plo = img + rlo[s] * RS + 8 * p;
+    const char* phi = img + rhi[s] * RS + 8 * p;
+#pragma unroll
+    for (int db = 0; db < 2 * KK; ++db) {
+      const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(plo + 32 * db));
+      const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(phi + 32 * db));
+      const bf16x8 av = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) o[db][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, coef[s][nb], o[db][nb], 0, 0, 0);
+    }
+  }
+}
+
+// emit_rows for 8 waves; only rows [rlo, rhi) of the wave's 32 (wave-uniform bounds) are stored and enter the column sums
+template <int KK>
+__device__ __forceinline__ void emit_rows8(char* img, float* red, bf16_t* __restrict__ out, int ldo, int n0, int rlo, int rhi, float scale,
+                                           const f32x4 (&o)[2 * KK][2], float* __restrict__ slab) {
+  constexpr int HD = 32 * KK, RSO = HD * 2 + 16, CPR = 4 * KK;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l15 = lane & 15, g = lane >> 4;
+  char* mine = img + wave * WROWS * RSO;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();                                         // every wave has finished reading the image
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    char* p = mine + (16 * nb + l15) * RSO + 8 * g;
+#pragma unroll
+    for (int db = 0; db < 2 * KK; ++db) {
+      bf16x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[db][nb][e] * scale);
+      *reinterpret_cast<bf16x4*>(p + 32 * db) = v;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int it = 0; it < CPR / 2; ++it) {
+    const int idx = it * 64 + lane, r = idx / CPR, ch = idx - r * CPR;
+    const uint4 v = *reinterpret_cast<const uint4*>(mine + r * RSO + ch * 16);
+    if (r >= rlo && r < rhi) *reinterpret_cast<uint4*>(out + (size_t)(n0 + r) * ldo + ch * 8) = v;
+  }
+  if (slab) {
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (lane < HD / 4) {
+      for (int r = rlo; r < rhi; ++r) {
+        const uint2 u = *reinterpret_cast<const uint2*>(mine + r * RSO + lane * 8);
+        cs[0] += bf16_lo(u.x); cs[1] += bf16_hi(u.x); cs[2] += bf16_lo(u.y); cs[3] += bf16_hi(u.y);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[wave * HD + 4 * lane + j] = cs[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < HD) {
+      const int t = threadIdx.x;
+      slab[t] = ((red[t] + red[HD + t]) + (red[2 * HD + t] + red[3 * HD + t])) + ((red[4 * HD + t] + red[5 * HD + t]) + (red[6 * HD + t] + red[7 * HD + t]));
+    }
+  }
+}
+
+template <int KK>
+struct FusedLds {
+  static constexpr int HD = 32 * KK;
+  static constexpr int PARK = 8 * WROWS * (HD * 2 + 16), ROWS = FROWS * HD * 2;
+  static constexpr int IMG = (((PARK > ROWS ? PARK : ROWS) + 1023) / 1024) * 1024;
+  static constexpr int XT = FROWS * 64;                  // one transposed coefficient array: 256 keys x 32 queries x bf16
+  static constexpr int TOTAL = IMG + 2 * XT + 8 * HD * 4;
+};
+
+template <int KK>
+__global__ __launch_bounds__(512, 1) void band_mfma_bwd_fused_kernel(const BandArgs a, int tk, int halo, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char img[];
+  constexpr int NKB = 4, NS = 2;
+  char* xp = img + FusedLds<KK>::IMG;
+  char* xs = xp + FusedLds<KK>::XT;
+  float* red = reinterpret_cast<float*>(xs + FusedLds<KK>::XT);
+  int tile, h, b;
+  decode_block(ntiles, a.heads, ntiles * a.heads * a.B, tile, h, b);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l15 = lane & 15, g = lane >> 4;
+  const int t0 = tile * tk, qs = t0 - halo, fq = tk + 2 * halo;
+  const int w = a.radius, W = 2 * w + 1, hd = a.hd, ld = 3 * a.D;
+  const DocView doc = doc_view(a, b);
+  const int L = doc.Lb;
+  float* slab = a.bias_slab ? a.bias_slab + (size_t)(b * ntiles + tile) * ld + h * hd : nullptr;
+  if (t0 >= L) {
+    if (slab && threadIdx.x < hd) { slab[threadIdx.x] = 0.f; slab[a.D + threadIdx.x] = 0.f; slab[2 * a.D + threadIdx.x] = 0.f; }
+    return;
+  }
+  const int khi = min(t0 + tk, L);                         // this workgroup's key rows (and the queries whose dQ it writes): [t0, khi)
+  const int io = halo ? qs - w : 0;                        // matrix row of image row 0
+  const int nst = min(FROWS, ((L - io + 15) / 16) * 16);   // staged rows (the rest of the image is never addressed)
+  const bf16_t* qbase = reinterpret_cast<const bf16_t*>(a.qkv) + (size_t)doc.base * ld + h * hd;
+  const bf16_t* dcbase = reinterpret_cast<const bf16_t*>(a.dctx) + (size_t)doc.base * a.D + h * hd;
+  bf16_t* out = reinterpret_cast<bf16_t*>(a.dqkv) + (size_t)doc.base * ld + h * hd;
+  const int rq = (lane & 15) >> 2;                         // the lane's row inside a 4-row group of the transposing read
+
+  stage_dma8<KK>(img, qbase + a.D, ld, io, nst, L);        // K rows
+
+  // ---- part 1: this wave's 32 query rows ------------------------------------------------------------------------------------------
+  const int q0 = qs + WROWS * wave;
+  const bool act1 = WROWS * wave < fq && q0 < L && q0 + WROWS > 0;
+  bf16x8 coef[NS][2];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) { coef[s][0] = bf16x8{}; coef[s][1] = bf16x8{}; }
+  if (act1) {
+    float pr[NKB][2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int i = q0 + 16 * qb + l15;
+      const bool iok = i >= 0 && i < L;
+      const float* prow = a.probs + ((size_t)(doc.base + min(max(i, 0), L - 1)) * a.heads + h) * a.slots;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * kb + 4 * g + r - 16 * qb - l15;
+          pr[kb][qb][r] = (iok && c >= 0 && c < W) ? prow[c] : 0.f;
+        }
+    }
+    f32x4 acc[NKB][2];
+    zero_acc<NKB>(acc);
+    qk_phase<KK, NKB>(qbase + 2 * a.D, ld, q0 - w, dcbase, a.D, q0, L, lane, acc);      // dP^T
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int i = q0 + 16 * qb + l15;
+      const bool iok = i >= 0 && i < L;
+      float pd[NKB][4];                                    // the probabilities as they multiplied V (dropout applied)
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = pr[kb][qb][r];
+          if (a.drop_thr) {
+            const int c = 16 * kb + 4 * g + r - 16 * qb - l15;
+            const bool keep = band_keep(a, doc.base + i, h, c);
+            acc[kb][qb][r] = keep ? acc[kb][qb][r] * a.drop_scale : 0.f;
+            x = keep ? x * a.drop_scale : 0.f;
+          }
+          pd[kb][r] = x;
+        }
+      float delta = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) delta = fmaf(pr[kb][qb][r], acc[kb][qb][r], delta);
+      delta = quad_sum(delta);
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pr[kb][qb][r] *= (acc[kb][qb][r] - delta);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        bf16x8 c8;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { c8[r] = (bf16_t)pr[2 * s][qb][r]; c8[4 + r] = (bf16_t)pr[2 * s + 1][qb][r]; }
+        coef[s][qb] = c8;
+      }
+      // transposed hand-over to part 2: XT[key - t0][query & 31]
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int jl = q0 - w + 16 * kb + 4 * g + r - t0, c = 16 * kb + 4 * g + r - 16 * qb - l15;
+          if (iok && jl >= 0 && jl < tk && c >= 0 && c < W) {
+            const int off = jl * 64 + (i & 31) * 2;
+            *reinterpret_cast<bf16_t*>(xp + off) = (bf16_t)pd[kb][r];
+            *reinterpret_cast<bf16_t*>(xs + off) = (bf16_t)pr[kb][qb][r];
+          }
+        }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the K image has landed; this wave's XT entries are written
+  __syncthreads();
+  f32x4 o[2 * KK][2];
+  zero_acc<2 * KK>(o);
+  int rlo[NS], rhi[NS];
+  if (act1) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int r0 = q0 - w - io + 32 * s + 4 * g + rq;
+      rlo[s] = min(max(r0, 0), nst - 1); rhi[s] = min(max(r0 + 16, 0), nst - 1);
+    }
+    cv_phase_rows<KK, NS>(img, rlo, rhi, coef, lane, o);
+  }
+  emit_rows8<KK>(img, red, out, ld, q0, min(max(t0 - q0, 0), WROWS), min(max(khi - q0, 0), WROWS), a.q_scale, o, slab);                // dQ
+
+  // ---- part 2: this wave's 32 key rows --------------------------------------------------------------------------------------------
+  const int j0 = t0 + WROWS * wave;
+  const bool act2 = WROWS * wave < tk && j0 < L;
+  const int jhi = min(max(khi - j0, 0), WROWS);
+  auto load_xt = [&](const char* xt) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const int j = j0 + 16 * nb + l15, i8 = j0 - 16 + 32 * s + 8 * g;
+        const s16x8 raw = *reinterpret_cast<const s16x8*>(xt + (j - t0) * 64 + (i8 & 31) * 2);
+        s16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int i = i8 + e, c = j - i + w;
+          v[e] = (i >= 0 && i < L && j < L && c >= 0 && c < W) ? raw[e] : (short)0;
+        }
+        coef[s][nb] = __builtin_bit_cast(bf16x8, v);
+      }
+  };
+  auto kv_rows = [&]() {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int r0 = j0 - 16 - io + 32 * s + 8 * g + rq;
+      rlo[s] = min(max(r0, 0), nst - 1); rhi[s] = min(max(r0 + 4, 0), nst - 1);
+    }
+  };
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();                                         // every wave is done with the K image and with its parked tile
+  stage_dma8<KK>(img, dcbase, a.D, io, nst, L);            // dCtx rows
+  if (act2) load_xt(xp);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  zero_acc<2 * KK>(o);
+  if (act2) { kv_rows(); cv_phase_rows<KK, NS>(img, rlo, rhi, coef, lane, o); }
+  emit_rows8<KK>(img, red, out + 2 * a.D, ld, j0, 0, act2 ? jhi : 0, 1.f, o, slab ? slab + 2 * a.D : nullptr);                         // dV
+
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  stage_dma8<KK>(img, qbase, ld, io, nst, L);              // (scaled) q rows
+  if (act2) load_xt(xs);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  zero_acc<2 * KK>(o);
+  if (act2) { kv_rows(); cv_phase_rows<KK, NS>(img, rlo, rhi, coef, lane, o); }
+  emit_rows8<KK>(img, red, out + a.D, ld, j0, 0, act2 ? jhi : 0, 1.f, o, slab ? slab + a.D : nullptr);                                 // dK
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 template <typename K>
@@ -511,8 +780,41 @@ int mts_band_mfma_fwd(const BandArgs& a, hipStream_t st) {
   return dispatch<0>(a, st, "mts_band_attn_fwd(mfma)");
 }
 
-int mts_band_mfma_bwd(const BandArgs& a, hipStream_t st) {
+static thread_local int g_band_fused = 1;       // mts_set_option("band_fused_bwd", 0): the two-kernel backward (A/B testing)
+void mts_band_set_fused(int on) { g_band_fused = on; }
+
+template <int KK>
+static int launch_fused(const BandArgs& a, hipStream_t st, int* slab_rows) {
+  auto k = band_mfma_bwd_fused_kernel<KK>;
+  const size_t lds = FusedLds<KK>::TOTAL;
+  static std::atomic<bool> attr{false};
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { mts_set_error("mts_band_attn_bwd(fused): hipFuncSetAttribute: %s", hipGetErrorString(e)); return MTS_ERR_LAUNCH; }
+    attr = true;
+  }
+  const int halo = a.L <= FROWS ? 0 : 16, tk = FROWS - (halo ? 64 : 0);      // 256 rows, or 192 key rows inside 224 query rows
+  const int ntiles = ceil_div(a.L, tk);
+  hipLaunchKernelGGL(k, dim3(ntiles * a.heads * a.B), dim3(512), lds, st, a, tk, halo, ntiles);
+  MTS_LAUNCH_CHECK("mts_band_attn_bwd(fused)");
+  *slab_rows = a.B * ntiles;
+  return MTS_OK;
+}
+
+int mts_band_mfma_bwd(const BandArgs& a, hipStream_t st, int* slab_rows) {
   if (!covered(a)) return -1;
+  *slab_rows = a.B * ceil_div(a.L, TROWS);
+  if (g_band_fused && pick_nkb(a) == 4 && a.hd <= 224) {
+    switch (a.hd / 32) {
+      case 1: return launch_fused<1>(a, st, slab_rows);
+      case 2: return launch_fused<2>(a, st, slab_rows);
+      case 3: return launch_fused<3>(a, st, slab_rows);
+      case 4: return launch_fused<4>(a, st, slab_rows);
+      case 5: return launch_fused<5>(a, st, slab_rows);
+      case 6: return launch_fused<6>(a, st, slab_rows);
+      case 7: return launch_fused<7>(a, st, slab_rows);
+    }
+  }
   int rc = dispatch<1>(a, st, "mts_band_attn_bwd(mfma q)");
   if (rc) return rc;
   return dispatch<2>(a, st, "mts_band_attn_bwd(mfma kv)");

@@ -12,7 +12,7 @@ struct BandArgs {
   float q_scale;
   const int32_t* row0;  // packed batches: first row of document b (rows of a document are contiguous, only its `lengths[b]` valid rows exist); NULL = padded [B, L]
   float drop_scale; uint32_t drop_thr; uint64_t drop_seed;   // dropout on the attention probabilities (drop_thr = 0: off)
-  float* bias_slab;   // MFMA backward: per-(document, 128-row tile) column sums of dqkv, [B*ceil(L/128)][3D], or NULL
+  float* bias_slab;   // MFMA backward: per-(document, tile) column sums of dqkv, [<= B*ceil(L/128)][3D], or NULL
   int img_bytes;      // MFMA kernels: size of the staged-row LDS image
 };
 
@@ -44,4 +44,4 @@ __device__ __forceinline__ bool band_keep(const BandArgs& a, int grow, int h, in
 // band_attn_mfma.hip: returns MTS_OK after launching, or -1 when the shape is outside what the MFMA kernels cover
 // (the caller then takes the generic kernels).
 int mts_band_mfma_fwd(const BandArgs& a, hipStream_t st);
-int mts_band_mfma_bwd(const BandArgs& a, hipStream_t st);
+int mts_band_mfma_bwd(const BandArgs& a, hipStream_t st, int* slab_rows);   // *slab_rows: rows of bias_slab the kernels filled

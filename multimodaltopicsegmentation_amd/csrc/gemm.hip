@@ -683,6 +683,7 @@ extern "C" int mts_gemm_last_plan(int* tile, int* splits) {
 }
 
 void mts_band_set_mfma(int on);   // band_attn.hip
+void mts_band_set_fused(int on);  // band_attn_mfma.hip
 static thread_local int g_f32_mfma = 1;                   // fp32 (parity mode) GEMM on v_mfma_f32_16x16x4_f32; 0 = VALU kernel
 static thread_local int g_big_min_k = 256;                // smallest K the big-tile kernels are considered for ("gemm_big_min_k")
 static thread_local int g_gemm_variant = 0;               // A/B switch of the big-tile kernels (GemmArgs::variant)
@@ -701,6 +702,7 @@ extern "C" int mts_set_option(const char* key, int value) {
   if (!strcmp(key, "gemm_big_min_k")) { g_big_min_k = value; return MTS_OK; }
   if (!strcmp(key, "gemm_f32_mfma")) { g_f32_mfma = value; return MTS_OK; }
   if (!strcmp(key, "band_mfma")) { mts_band_set_mfma(value); return MTS_OK; }
+  if (!strcmp(key, "band_fused_bwd")) { mts_band_set_fused(value); return MTS_OK; }
   if (!strcmp(key, "lstm_pair_spin_limit")) { mts_lstm_pair_set_spin_limit(value); return MTS_OK; }
   if (!strcmp(key, "lstm_pair_max_pairs")) { mts_lstm_pair_set_max_pairs(value); return MTS_OK; }
   if (!strcmp(key, "lstm_parts")) { mts_lstm_pair_set_parts(value); return MTS_OK; }

@@ -76,8 +76,8 @@ def test_pair_kernels_against_oracle_and_across_launches(B, Lq, lengths, dt):
         assert torch.equal(o2, out) and torch.equal(x2, dxp) and torch.equal(w2, dwhh)
 
 
-def _pair_run(ops, B, Lq, lengths, seed=0):
-    H, dt = 256, torch.bfloat16
+def _pair_run(ops, B, Lq, lengths, seed=0, dt=torch.bfloat16):
+    H = 256
     N = B * Lq
     xd = _rnd(N, 8 * H, seed=seed + 1).to(dt).to(DEV)
     wd = _rnd(2, 4 * H, H, seed=seed + 2, scale=1 / math.sqrt(H)).to(DEV)
@@ -95,7 +95,8 @@ def _pair_run(ops, B, Lq, lengths, seed=0):
     return out, dxp, dwhh
 
 
-def test_pair_path_splits_large_batches_into_resident_launches():
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float32], ids=['bf16', 'fp32'])
+def test_pair_path_splits_large_batches_into_resident_launches(dt):
     """A pair needs both of its workgroups resident (one per CU): a launch covers at most 64 pairs = 512 documents x 2
     directions, larger batches run as consecutive launches over document ranges.  B = 1100 (three launches: 512 + 512 + 76)
     must equal, bit for bit, the same documents run in batches that fit one launch; and forcing 8 pairs per launch on a
@@ -105,40 +106,41 @@ def test_pair_path_splits_large_batches_into_resident_launches():
     g = torch.Generator().manual_seed(5)
     lengths = torch.randint(1, Lq + 1, (B,), generator=g).tolist()
     lengths[0] = lengths[511] = lengths[512] = lengths[1099] = Lq
-    out, dxp, dwhh = _pair_run(ops, B, Lq, lengths)
+    out, dxp, dwhh = _pair_run(ops, B, Lq, lengths, dt=dt)
     assert not torch.isnan(out.float()).any() and not torch.isnan(dxp.float()).any()
     L.check_async()
     H = 256
     # the same rows through launches of <= 512 documents each: slice the inputs exactly as _pair_run builds them
     N = B * Lq
-    xd = _rnd(N, 8 * H, seed=1).to(torch.bfloat16).to(DEV)
+    xd = _rnd(N, 8 * H, seed=1).to(dt).to(DEV)
     wd = _rnd(2, 4 * H, H, seed=2, scale=1 / math.sqrt(H)).to(DEV)
     bd = _rnd(2, 4 * H, seed=3, scale=0.1).to(DEV)
     for b0, b1 in ((0, 400), (400, 800), (800, 1100)):
         n = (b1 - b0) * Lq
-        o = torch.empty(n, 2 * H, dtype=torch.bfloat16, device=DEV)
-        gt = torch.empty(n, 8 * H, dtype=torch.bfloat16, device=DEV)
+        o = torch.empty(n, 2 * H, dtype=dt, device=DEV)
+        gt = torch.empty(n, 8 * H, dtype=dt, device=DEV)
         c = torch.empty(n, 2 * H, device=DEV)
         ops.lstm_fwd(xd[b0 * Lq:b1 * Lq].contiguous(), wd, bd, torch.tensor(lengths[b0:b1], dtype=torch.int32, device=DEV), b1 - b0, Lq, H, 2, o, gt, c)
         assert torch.equal(o, out[b0 * Lq:b1 * Lq]), (b0, b1)
     try:
-        ref = _pair_run(ops, 100, 9, [9] * 50 + [3] * 50, seed=7)
+        ref = _pair_run(ops, 100, 9, [9] * 50 + [3] * 50, seed=7, dt=dt)
         L.lib.mts_set_option(b'lstm_pair_max_pairs', 8)
-        got = _pair_run(ops, 100, 9, [9] * 50 + [3] * 50, seed=7)
+        got = _pair_run(ops, 100, 9, [9] * 50 + [3] * 50, seed=7, dt=dt)
         for a, r in zip(got, ref):
             assert torch.equal(a, r)
     finally:
         L.lib.mts_set_option(b'lstm_pair_max_pairs', 64)
 
 
-def test_pair_timeout_is_reported_by_the_next_call():
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float32], ids=['bf16', 'fp32'])
+def test_pair_timeout_is_reported_by_the_next_call(dt):
     """A partner poll that gives up used to be silent (status word set on the device, never read).  With the re-poll budget
     forced to 0 every hand-off that is not already there times out: the launch completes (bounded spins), and the NEXT
     mts_lstm_* call -- or mts_async_status() -- returns MTS_ERR_TIMEOUT once; after that the library is usable again."""
     from multimodaltopicsegmentation_amd import ops, _lib as L
     try:
         L.lib.mts_set_option(b'lstm_pair_spin_limit', 0)
-        _pair_run(ops, 32, 40, [40] * 32)                      # poisoned launches; the backward call may already report the forward's timeout
+        _pair_run(ops, 32, 40, [40] * 32, dt=dt)               # poisoned launches; the backward call may already report the forward's timeout
         raised = False
     except L.MtsError as e:
         raised = 'timed out' in str(e)
@@ -150,7 +152,7 @@ def test_pair_timeout_is_reported_by_the_next_call():
             L.check_async()
     L.lib.mts_async_status()                                   # drain whatever the second poisoned launch left
     L.check_async()                                            # clean again
-    out, dxp, _ = _pair_run(ops, 32, 40, [40] * 32)
+    out, dxp, _ = _pair_run(ops, 32, 40, [40] * 32, dt=dt)
     assert not torch.isnan(out.float()).any() and not torch.isnan(dxp.float()).any()
     L.check_async()
 
