@@ -72,7 +72,9 @@ const char* mts_version(void);
  * (fp32 GEMM on v_mfma_f32_16x16x4_f32) | 0 (VALU kernel, bitwise the same results) ; "gemm_tile" = 0 (cost model) | 128 | 224 | 256 ; "gemm_glds" = 1 (LDS-DMA staging) | 0 (register
  * staging) ; "gemm_splits" = 0 (cost model) | n ; "gemm_order" = 1 (L2-blocked tile order) | 0 ; "gemm_chain" = 0 | 1 (split-K
  * of the 128x128 kernel accumulates in place) ; "gemm_deep" = 1 (four-buffer copy pipeline of the 128x128 kernel for grids of at
- * most one workgroup per CU) | 0 ; "band_mfma" = 1 | 0 ; "lstm_pair_spin_limit" = re-polls before a CU-pair LSTM workgroup gives
+ * most one workgroup per CU) | 0 ; "band_mfma" = 1 | 0 ; "band_fused_bwd" = 1 (bf16 band attention backward in one pass where it applies:
+ * radius <= 15, head dim <= 224) | 0 (two kernels) ; "lstm_parts" = 4 (CU-quad recurrences at H = 256, bf16 and fp32) | 2 (CU pair, bf16) ;
+ * "lstm_pair_spin_limit" = re-polls before a CU-pair LSTM workgroup gives
  * up on its partner (-1 = default 2^22; tests use 0) ; "lstm_pair_max_pairs" = CU pairs per recurrence launch (1..64, default 64) */
 int mts_set_option(const char* key, int value);
 /* Device-side errors that cannot be known at launch time, polled WITHOUT synchronising (a pinned host word the kernels write
@@ -221,7 +223,7 @@ int mts_band_attn_fwd(void* stream, int dtype, int B, int L, int D, int heads, i
                       const void* qkv, const int32_t* lengths, void* ctx, float* probs, const int32_t* row0,
                       float drop_p, uint64_t drop_seed);
 /* dqkv [B*L, 3D] (dq already multiplied by q_scale so it is the gradient wrt the unscaled projection);
- * dscores: fp32 scratch of the same size as probs.  dbias (optional): fp32 [3D] column sums of dqkv as stored =
+ * dscores: fp32 scratch of the same size as probs (the one-pass bf16 kernel leaves it untouched: dS stays on the chip).  dbias (optional): fp32 [3D] column sums of dqkv as stored =
  * the gradient of the q/k/v biases (modeling_longformer.py:504-506), produced from the kernels' output tiles instead of
  * re-reading dqkv; needs `workspace` of mts_band_attn_bwd_workspace(B, L, D) bytes.  Bitwise reproducible. */
 size_t mts_band_attn_bwd_workspace(int B, int L, int D);

@@ -33,7 +33,10 @@ for a in ('bilstm', 'bilstm_crf', 'latefusion512'):
 cp(os.path.join(src, 'infer_latency.jsonl'), f'{tag}_infer_latency.jsonl')
 cp(os.path.join(src, 'bench_fp32.json'), f'{tag}_fp32_bench.json')
 cp(os.path.join(src, 'bench_fp32_bilstm.json'), f'{tag}_fp32_bilstm_bench.json')
-for f, n in (('bench_dp1.json', 'dp1_bench.json'), ('bench_dp1_latefusion512.json', 'dp1_latefusion512_bench.json'), ('h2d.jsonl', 'h2d.jsonl')):
+if glob.glob(os.path.join(src, 'trace_fp32_bilstm/**/*kernel_stats.csv'), recursive=True):
+    cp(one('trace_fp32_bilstm/**/*kernel_stats.csv'), f'{tag}_fp32_bilstm_kernel_stats.csv')
+for f, n in (('bench_dp1.json', 'dp1_bench.json'), ('bench_dp1_latefusion512.json', 'dp1_latefusion512_bench.json'), ('h2d.jsonl', 'h2d.jsonl'),
+             ('bench_dp1_rs_ag.json', 'dp1_rs_ag_bench.json'), ('band_fused_ab.txt', 'band_fused_ab.txt'), ('step_ab_band.txt', 'step_ab_band.txt')):
     if os.path.exists(os.path.join(src, f)):
         cp(os.path.join(src, f), f'{tag}_{n}')
 # HBM-side traffic per kernel (stamped with the kernel-source hash; bench.py reads r03_pmc_traffic.json)
