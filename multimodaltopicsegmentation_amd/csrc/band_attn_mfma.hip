@@ -451,7 +451,8 @@ __global__ __launch_bounds__(256, OCC) void band_mfma_bwd_kv_kernel(const BandAr
 // sentences is ONE tile (no halo at all: the BASELINE shape); longer documents are cut into tiles of 192 key rows whose 224 query
 // rows include a 16-row halo on either side (key j needs the coefficients of queries j - w .. j + w, and a query's dS needs its whole
 // window, so halo queries are recomputed by both neighbours: 224 / 192 of the per-query work).
-//   part 1 (wave = 32 query rows, as band_mfma_bwd_q_kernel): dP^T = V.dCtx^T, dS = P (dP - rowsum(P dP)), dQ = q_scale dS.K from the K
+//   part 1 (wave = 32 query rows, as band_mfma_bwd_q_kernel): dP^T = V.dCtx^T (dCtx fragments out of the dCtx image, which part 2 needs
+//           anyway: dCtx is fetched once), dS = P (dP - rowsum(P dP)), and -- after dV -- dQ = q_scale dS.K from the K
 //           image; P (dropped form) and dS are left in LDS as bf16, transposed: XT[key - t0][query & 31] (a key's 2w + 1 queries are
 //           distinct modulo 32), 16 KB each;
 //   part 2 (wave = 32 key rows, as band_mfma_bwd_kv_kernel): the B operand of key j is 8 consecutive queries = ONE 16-byte LDS read of
@@ -576,16 +577,16 @@ __global__ __launch_bounds__(512, 1) void band_mfma_bwd_fused_kernel(const BandA
   bf16_t* out = reinterpret_cast<bf16_t*>(a.dqkv) + (size_t)doc.base * ld + h * hd;
   const int rq = (lane & 15) >> 2;                         // the lane's row inside a 4-row group of the transposing read
 
-  stage_dma8<KK>(img, qbase + a.D, ld, io, nst, L);        // K rows
+  stage_dma8<KK>(img, dcbase, a.D, io, nst, L);            // dCtx rows: B operand of dP in part 1, R operand of dV in part 2
 
   // ---- part 1: this wave's 32 query rows ------------------------------------------------------------------------------------------
   const int q0 = qs + WROWS * wave;
   const bool act1 = WROWS * wave < fq && q0 < L && q0 + WROWS > 0;
-  bf16x8 coef[NS][2];
+  bf16x8 coefq[NS][2];                                     // dS^T of this wave's queries: B operand of dQ (used after the dV phase)
 #pragma unroll
-  for (int s = 0; s < NS; ++s) { coef[s][0] = bf16x8{}; coef[s][1] = bf16x8{}; }
+  for (int s = 0; s < NS; ++s) { coefq[s][0] = bf16x8{}; coefq[s][1] = bf16x8{}; }
+  float pr[NKB][2][4];
   if (act1) {
-    float pr[NKB][2][4];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       const int i = q0 + 16 * qb + l15;
@@ -599,9 +600,35 @@ __global__ __launch_bounds__(512, 1) void band_mfma_bwd_fused_kernel(const BandA
           pr[kb][qb][r] = (iok && c >= 0 && c < W) ? prow[c] : 0.f;
         }
     }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the dCtx image has landed
+  __syncthreads();
+  if (act1) {
     f32x4 acc[NKB][2];
     zero_acc<NKB>(acc);
-    qk_phase<KK, NKB>(qbase + 2 * a.D, ld, q0 - w, dcbase, a.D, q0, L, lane, acc);      // dP^T
+    {                                                      // dP^T = V . dCtx^T: V fragments straight from L2, dCtx fragments out of the image
+      constexpr int RS = 64 * KK;
+      bf16x8 yq[2][KK];
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const int row = min(max(q0 - io + 16 * qb + l15, 0), nst - 1);
+        const char* py = img + row * RS + 16 * g;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) yq[qb][kk] = *reinterpret_cast<const bf16x8*>(py + 64 * kk);
+      }
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const int row = min(max(q0 - w + 16 * kb + l15, 0), L - 1);
+        const bf16_t* px = qbase + 2 * a.D + (size_t)row * ld + 8 * g;
+        bf16x8 xk[KK];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) xk[kk] = *reinterpret_cast<const bf16x8*>(px + 32 * kk);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb) acc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xk[kk], yq[qb][kk], acc[kb][qb], 0, 0, 0);
+      }
+    }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       const int i = q0 + 16 * qb + l15;
@@ -635,7 +662,7 @@ __global__ __launch_bounds__(512, 1) void band_mfma_bwd_fused_kernel(const BandA
         bf16x8 c8;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { c8[r] = (bf16_t)pr[2 * s][qb][r]; c8[4 + r] = (bf16_t)pr[2 * s + 1][qb][r]; }
-        coef[s][qb] = c8;
+        coefq[s][qb] = c8;
       }
       // transposed hand-over to part 2: XT[key - t0][query & 31]
 #pragma unroll
@@ -651,25 +678,16 @@ __global__ __launch_bounds__(512, 1) void band_mfma_bwd_fused_kernel(const BandA
         }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the K image has landed; this wave's XT entries are written
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's XT entries are written
   __syncthreads();
-  f32x4 o[2 * KK][2];
-  zero_acc<2 * KK>(o);
-  int rlo[NS], rhi[NS];
-  if (act1) {
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int r0 = q0 - w - io + 32 * s + 4 * g + rq;
-      rlo[s] = min(max(r0, 0), nst - 1); rhi[s] = min(max(r0 + 16, 0), nst - 1);
-    }
-    cv_phase_rows<KK, NS>(img, rlo, rhi, coef, lane, o);
-  }
-  emit_rows8<KK>(img, red, out, ld, q0, min(max(t0 - q0, 0), WROWS), min(max(khi - q0, 0), WROWS), a.q_scale, o, slab);                // dQ
 
-  // ---- part 2: this wave's 32 key rows --------------------------------------------------------------------------------------------
+  // ---- part 2a: dV of this wave's 32 key rows, out of the dCtx image that is already there ---------------------------------------------
   const int j0 = t0 + WROWS * wave;
   const bool act2 = WROWS * wave < tk && j0 < L;
   const int jhi = min(max(khi - j0, 0), WROWS);
+  bf16x8 coef[NS][2];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) { coef[s][0] = bf16x8{}; coef[s][1] = bf16x8{}; }
   auto load_xt = [&](const char* xt) {
 #pragma unroll
     for (int s = 0; s < NS; ++s)
@@ -686,6 +704,7 @@ __global__ __launch_bounds__(512, 1) void band_mfma_bwd_fused_kernel(const BandA
         coef[s][nb] = __builtin_bit_cast(bf16x8, v);
       }
   };
+  int rlo[NS], rhi[NS];
   auto kv_rows = [&]() {
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -693,16 +712,29 @@ __global__ __launch_bounds__(512, 1) void band_mfma_bwd_fused_kernel(const BandA
       rlo[s] = min(max(r0, 0), nst - 1); rhi[s] = min(max(r0 + 4, 0), nst - 1);
     }
   };
+  f32x4 o[2 * KK][2];
+  zero_acc<2 * KK>(o);
+  if (act2) { load_xt(xp); kv_rows(); cv_phase_rows<KK, NS>(img, rlo, rhi, coef, lane, o); }
+  emit_rows8<KK>(img, red, out + 2 * a.D, ld, j0, 0, act2 ? jhi : 0, 1.f, o, slab ? slab + 2 * a.D : nullptr);                         // dV
+
+  // ---- part 1, continued: dQ = q_scale dS.K ---------------------------------------------------------------------------------------------
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __syncthreads();                                         // every wave is done with the K image and with its parked tile
-  stage_dma8<KK>(img, dcbase, a.D, io, nst, L);            // dCtx rows
-  if (act2) load_xt(xp);
+  __syncthreads();                                         // every wave is done with the dCtx image and with its parked tile
+  stage_dma8<KK>(img, qbase + a.D, ld, io, nst, L);        // K rows
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   zero_acc<2 * KK>(o);
-  if (act2) { kv_rows(); cv_phase_rows<KK, NS>(img, rlo, rhi, coef, lane, o); }
-  emit_rows8<KK>(img, red, out + 2 * a.D, ld, j0, 0, act2 ? jhi : 0, 1.f, o, slab ? slab + 2 * a.D : nullptr);                         // dV
+  if (act1) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int r0 = q0 - w - io + 32 * s + 4 * g + rq;
+      rlo[s] = min(max(r0, 0), nst - 1); rhi[s] = min(max(r0 + 16, 0), nst - 1);
+    }
+    cv_phase_rows<KK, NS>(img, rlo, rhi, coefq, lane, o);
+  }
+  emit_rows8<KK>(img, red, out, ld, q0, min(max(t0 - q0, 0), WROWS), min(max(khi - q0, 0), WROWS), a.q_scale, o, slab);                // dQ
 
+  // ---- part 2b: dK ------------------------------------------------------------------------------------------------------------------------
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
   stage_dma8<KK>(img, qbase, ld, io, nst, L);              // (scaled) q rows

@@ -241,6 +241,9 @@ __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
   // register file, and as global loads inside the row loop every one of them made the compiler wait for the next row's prefetch
   __shared__ __attribute__((aligned(16))) float gam_s[NV * 256];
   __shared__ __attribute__((aligned(16))) float hw_s[EMB ? 1 : 4][EMB ? 4 : NV * 256];
+  // EMB: the running sum of a wave's current task (one position, a chunk of documents) lives in LDS, not in 4 NV registers: with them the
+  // D = 1792 instance spilled 16 registers to scratch, and a scratch reload waits (vmcnt is in order) for the next row's prefetch as well
+  __shared__ __attribute__((aligned(16))) float task_s[EMB ? ROW_WAVES : 1][EMB ? NV * 256 : 4];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row / task bookkeeping lives in scalar registers
   const int col0 = WIDE ? (int)blockIdx.y * (NV * 256) : 0;
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
   }
   __syncthreads();
   float acc[NA][NV][4];          // HG: S_c;  else [0] = dgamma, [1] = dbeta
-  float dxs[NV][4];              // colsum(dx); EMB: the running sum of the current task (one position, a chunk of documents)
+  float dxs[NV][4];              // colsum(dx) (EMB: unused, see task_s)
   float tsum[HG ? NHG : 1];
 #pragma unroll
   for (int i = 0; i < NV; ++i)
@@ -266,6 +269,10 @@ __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
     }
 #pragma unroll
   for (int c = 0; c < (HG ? NHG : 1); ++c) tsum[c] = 0.f;
+  if constexpr (EMB) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) *reinterpret_cast<float4*>(&task_s[wave][4 * (lane + 64 * i)]) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 
   const float invD = 1.0f / (float)D;
   // the next row's x / dy are fetched (raw, storage precision) before the current row is reduced, so a wave always has
@@ -307,12 +314,15 @@ __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
     while (tb < tbend && !valid(tb, ti)) ++tb;
     return tb < tbend;
   };
-  auto write_task = [&](int t, const float (&v)[NV][4]) {
+  auto write_task = [&](int t) {                          // the finished task's sum: LDS -> dpos_part, and the LDS slot back to zero
     float* o = ea.dpos_part + (size_t)t * D;             // [chunk][i][D] = [t][D]
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int e = 4 * (lane + 64 * i);
-      if (FULL || e < D) store4<float>(o + e, v[i]);
+      float4* slot = reinterpret_cast<float4*>(&task_s[EMB ? wave : 0][EMB ? e : 0]);
+      const float4 v = *slot;
+      if (FULL || e < D) *reinterpret_cast<float4*>(o + e) = v;
+      *slot = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto skip_empty_tasks = [&]() {                         // leaves `task` on a task with at least one row, or >= ntasks
@@ -434,17 +444,20 @@ __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
         for (int j = 0; j < 4; ++j) {
           o[j] = rs * (gy[i][j] - s1 - xh[i][j] * s2);
           if constexpr (!EMB && sizeof(T) == 2) o[j] = to_f32(from_f32<T>(o[j]));   // sum what is stored (EMB: nothing is stored, fp32 throughout)
-          dxs[i][j] += o[j];
+          if constexpr (!EMB) dxs[i][j] += o[j];
         }
-        if constexpr (!EMB) store4<T>(dx + (size_t)row * D + e, o);
+        if constexpr (EMB) {
+          float4* slot = reinterpret_cast<float4*>(&task_s[wave][e]);
+          float4 t = *slot;
+          t.x += o[0]; t.y += o[1]; t.z += o[2]; t.w += o[3];
+          *slot = t;
+        } else {
+          store4<T>(dx + (size_t)row * D + e, o);
+        }
       }
     }
     if constexpr (EMB) {
-      if (done_task >= 0) {
-        write_task(done_task, dxs);
-#pragma unroll
-        for (int i = 0; i < NV; ++i) dxs[i][0] = dxs[i][1] = dxs[i][2] = dxs[i][3] = 0.f;
-      }
+      if (done_task >= 0) write_task(done_task);
     }
     row = nrow;
   }
