@@ -50,8 +50,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
     const int q = nt >> 3, rr = nt & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
   }
-  const int bm0 = (bid / ntn) * BM;
-  const int bn0 = (bid % ntn) * BN;
+  // ... walking the SHORTER side of the tile grid first: with 2 x 14 tiles (feed-forward weight gradient, M = 256) the two tiles of a column
+  // run side by side on one XCD and the wide operand's panel is fetched once, not once per tile row
+  const int bm0 = (ntm < ntn ? bid % ntm : bid / ntn) * BM;
+  const int bn0 = (ntm < ntn ? bid / ntm : bid % ntn) * BN;
   const int kbeg = blockIdx.z * a.ksplit;
   const int kend = min(a.K, kbeg + a.ksplit);
   const int nk = (kend - kbeg + BK - 1) / BK;

@@ -52,6 +52,8 @@ def _run(ops, L, fused, qkv, dctx, li32, B, Lq, D, heads, radius, row0=None, dro
     (2, 500, 192, 2, 7, [500, 300]),          # radius 7 (15 of 32 slots), hd 96
     (2, 300, 320, 2, 2, [300, 5]),            # radius 2, hd 160
     (1, 2437, 128, 2, 15, None),              # the longest real document (SURVEY: 2 437 sentences), hd 64
+    (2, 9, 64, 2, 1, [9, 4]),                 # radius 1, nine rows, hd 32
+    (1, 257, 32, 1, 15, None),                # one head of 32; one row past the single-tile limit (two tiles, the second holds one key)
 ])
 def test_fused_backward_against_oracle_and_the_two_kernel_form(B, Lq, D, heads, radius, lengths):
     from multimodaltopicsegmentation_amd import ops, _lib as L
