@@ -267,8 +267,9 @@ int mts_head_bwd_data(void* stream, int dtype, int rows, int D, int n_out, const
  * xproj: [B*L, ndir*4H] act dtype = x W_ih^T + b_ih for both directions (direction d owns columns
  *   d*4H..(d+1)*4H), produced by mts_gemm.  w_hh: fp32 [ndir, 4H, H]; b_hh: fp32 [ndir, 4H] (may be NULL),
  *   added to the gate pre-activations in fp32 inside the recurrence.
- * out: [B*L, ndir*H] act dtype.  gates (saved for backward): act dtype [B*L, ndir*4H] post-activation
- *   i,f,g,o; cells: fp32 [B*L, ndir*H].
+ * out: [B*L, ndir*H] act dtype.  gates (saved for backward): act dtype, B*L*ndir*4H elements, post-activation
+ *   i,f,g,o; cells: fp32, B*L*ndir*H elements.  Both are OPAQUE saved state handed unchanged to mts_lstm_bwd under the same options
+ *   (the generic kernels keep them as [B*L, ndir*4H] / [B*L, ndir*H]; the bf16 CU-quad recurrences keep step-major blocks).
  * ------------------------------------------------------------------------------------------- */
 /* workspace (both calls): mts_lstm_workspace(dtype, B, L, H, ndir) bytes */
 size_t mts_lstm_workspace(int dtype, int B, int L, int H, int ndir);

@@ -690,6 +690,16 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_quad_kernel(int B, int L, int
   const size_t b0 = (size_t)min(bdoc, B - 1) * L;
   const size_t grow0 = b0 * ldx + (size_t)d * 4 * H + u, orow0 = b0 * ldo + (size_t)d * H + u;
   const bf16_t* xbase = xproj + grow0;
+  // Saved state (gates, cells) in STEP-MAJOR blocks, private to this (document group, direction, part): what step s writes is one
+  // contiguous block [doc][gate][64 units] (8 KB of gates, 4 KB of cells), and the backward pass reads the same block at the same s.
+  // In the [document][time] layout of xproj / out a step touches 16 rows that lie L rows apart (16 DRAM pages and TLB entries per tensor
+  // and part); from 32 768 tokens on that cost 0.3 / 0.6 us per dependent step (64 x 512: 2.53 / 3.25 us against 2.27 / 2.68 at 64 x 256).
+  // The group's region is the rows of its documents in the caller's buffer: [direction][part][step][doc < ndg][...], ndg = documents
+  // present in the group, exactly ndg * L * ndir * 4H elements.
+  const int ndg = min(LP_DOCS, B - gx * LP_DOCS);
+  const size_t gstep = (size_t)ndg * 4 * HQ, cstep = (size_t)ndg * HQ;
+  bf16_t* gsave = gates + (size_t)gx * LP_DOCS * L * ldx + ((size_t)(d * 4 + p) * L) * gstep + (size_t)min(doc, ndg - 1) * 4 * HQ + ul;
+  float* csave = cells + (size_t)gx * LP_DOCS * L * ldo + ((size_t)(d * 4 + p) * L) * cstep + (size_t)min(doc, ndg - 1) * HQ + ul;
   auto load_x = [&](auto parc, int s) {                  // unconditional, clamped (see the pair kernel)
     constexpr int PAR = decltype(parc)::value;
     const int t = (d == 0) ? s : (len - 1 - s);
@@ -789,20 +799,23 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_quad_kernel(int B, int L, int
       __hip_atomic_store(mine + (ul >> 2) * 16 + doc, tag | hq.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(mine + 256 + (ul >> 2) * 16 + doc, tag | hq.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // 2) first poll of the partners' quarters, 3) x rows two steps ahead (queued before the bulk stores), then the poll check
+    // 2) poll the partners' quarters, 3) THEN request the x rows two steps ahead: the vector-memory counter retires in order, so a re-poll
+    //    (younger loads) also waits for every older load -- requested before the poll, the x rows had to land within the poll itself
+    //    (fine out of the Infinity Cache, not from HBM: 64 x 512); requested after it they have a whole step
     fetch_issue(s);
-    load_x(parc, s + 2);
     fetch(s);
+    load_x(parc, s + 2);
     // 4) saved state for the backward pass, last (ended documents store to the dump area)
     {
       const int t = (d == 0) ? s : (len - 1 - s);
-      bf16_t* gp = active ? gates + grow0 + (size_t)t * ldx : reinterpret_cast<bf16_t*>(dump + tid * 16);
-      float* cptr = active ? cells + orow0 + (size_t)t * ldo : reinterpret_cast<float*>(dump + tid * 16);
+      bf16_t* gp = active ? gsave + (size_t)s * gstep : reinterpret_cast<bf16_t*>(dump + tid * 16);
+      float* cptr = active ? csave + (size_t)s * cstep : reinterpret_cast<float*>(dump + tid * 16);
       bf16_t* optr = active ? out + orow0 + (size_t)t * ldo : reinterpret_cast<bf16_t*>(dump + tid * 16);
+      const int gs = active ? HQ : 0;
       *reinterpret_cast<uint2*>(gp) = pk4(gi);
-      *reinterpret_cast<uint2*>(gp + H) = pk4(gf);
-      *reinterpret_cast<uint2*>(gp + 2 * H) = pk4(gg);
-      *reinterpret_cast<uint2*>(gp + 3 * H) = pk4(go);
+      *reinterpret_cast<uint2*>(gp + gs) = pk4(gf);
+      *reinterpret_cast<uint2*>(gp + 2 * gs) = pk4(gg);
+      *reinterpret_cast<uint2*>(gp + 3 * gs) = pk4(go);
       *reinterpret_cast<float4*>(cptr) = make_float4(c[0], c[1], c[2], c[3]);
       *reinterpret_cast<uint2*>(optr) = hq;
     }
@@ -916,18 +929,23 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_quad_kernel(int B, int L, int
   const size_t b0 = (size_t)min(bdoc, B - 1) * L;
   const size_t grow0 = b0 * ldx + (size_t)d * 4 * H + u;
   const size_t orow0 = b0 * ldo + (size_t)d * H + u;
+  // saved state in the forward kernel's step-major blocks (lstm_fwd_quad_kernel): step s of this part is one contiguous block, and the
+  // previous cell state of step s is the cell block of step s - 1
+  const int ndg = min(LP_DOCS, B - gx * LP_DOCS);
+  const size_t gstep = (size_t)ndg * 4 * HQ, cstep = (size_t)ndg * HQ;
+  const bf16_t* gsave = gates + (size_t)gx * LP_DOCS * L * ldx + ((size_t)(d * 4 + p) * L) * gstep + (size_t)min(doc, ndg - 1) * 4 * HQ + ul;
+  const float* csave = cells + (size_t)gx * LP_DOCS * L * ldo + ((size_t)(d * 4 + p) * L) * cstep + (size_t)min(doc, ndg - 1) * HQ + ul;
   auto load_in = [&](int s, PairBwdIn& in) {             // unconditional, clamped (see the pair kernels)
-    const int sc = max(s, 0);
+    const int sc = min(max(s, 0), L - 1);
     const int t = min(max((d == 0) ? sc : (len - 1 - sc), 0), L - 1);
-    const int tp = min(max((d == 0) ? t - 1 : t + 1, 0), L - 1);
-    const bf16_t* gp = gates + grow0 + (size_t)t * ldx;
+    const bf16_t* gp = gsave + (size_t)sc * gstep;
     in.gi = *reinterpret_cast<const uint2*>(gp);
-    in.gf = *reinterpret_cast<const uint2*>(gp + H);
-    in.gg = *reinterpret_cast<const uint2*>(gp + 2 * H);
-    in.go = *reinterpret_cast<const uint2*>(gp + 3 * H);
+    in.gf = *reinterpret_cast<const uint2*>(gp + HQ);
+    in.gg = *reinterpret_cast<const uint2*>(gp + 2 * HQ);
+    in.go = *reinterpret_cast<const uint2*>(gp + 3 * HQ);
     in.dov = *reinterpret_cast<const uint2*>(dout + orow0 + (size_t)t * ldo);
-    in.ct = *reinterpret_cast<const float4*>(cells + orow0 + (size_t)t * ldo);
-    in.cp = *reinterpret_cast<const float4*>(cells + orow0 + (size_t)tp * ldo);
+    in.ct = *reinterpret_cast<const float4*>(csave + (size_t)sc * cstep);
+    in.cp = *reinterpret_cast<const float4*>(csave + (size_t)max(sc - 1, 0) * cstep);
   };
   bool dead = false;
   u64 v[3][2];
@@ -1309,8 +1327,8 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_quad_f32_kernel(int B, int L,
       for (int k2 = 0; k2 < 4; ++k2) __hip_atomic_store(mine + 256 * k2, tag | (u64)__float_as_uint(hq[k2]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     fetch_issue(s);
-    load_x(parc, s + 2);
     fetch(s);
+    load_x(parc, s + 2);                                   // after the poll (see the bf16 kernel)
     {
       const int t = (d == 0) ? s : (len - 1 - s);
       float* gp = active ? gates + grow0 + (size_t)t * ldx : reinterpret_cast<float*>(dump + tid * 16);

@@ -38,6 +38,8 @@ r2, f2, b2 = run(2, bwd)
 r4, f4, b4 = run(4, bwd)
 names = ['out', 'gates', 'cells', 'dxproj', 'dw_hh']
 for n, a, c in zip(names, r2, r4):
+    if n in ('gates', 'cells'):
+        continue                      # saved state: private layouts (the quad form keeps step-major blocks)
     d = (a.float() - c.float()).abs().max().item()
     print(f'{n:7s} equal={torch.equal(a, c)} max|diff|={d:.3e} max|ref|={a.float().abs().max().item():.3e}')
 print(f'pair: fwd {f2:.0f} us ({f2 / L:.2f} us/step) bwd {b2:.0f} us ({b2 / L:.2f} us/step)   quad: fwd {f4:.0f} us ({f4 / L:.2f} us/step) bwd {b4:.0f} us ({b4 / L:.2f} us/step)', flush=True)
