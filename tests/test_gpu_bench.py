@@ -49,14 +49,14 @@ def test_bench_ragged_counts_valid_sentences_only():
 
 
 def test_default_line_witnesses_the_other_baseline_configurations():
-    """the driver's BENCH record carries 20-step figures of configs[2] (focal and CRF heads), configs[4]'s per-GPU
+    """the driver's BENCH record carries 50-step figures of configs[2] (focal and CRF heads), configs[4]'s per-GPU
     workload and the fp32 parity mode (transformer and BiLSTM) under extra.other_configs; `value` / `roofline` stay on configs[1]."""
     j = _run('--steps', '3', '--warmup', '2', '--cpu-docs', '1', '--sustained-steps', '0')
     assert j['config']['workload'].startswith('BASELINE configs[1]')
     oc = j['extra']['other_configs']
     assert len(oc) == 5 and sum('configs[2]' in k for k in oc) == 3 and sum('configs[4]' in k for k in oc) == 1 and sum('fp32' in k for k in oc) == 2
     for k, v in oc.items():
-        assert v['steps'] == 20 and v['ms_per_step'] > 0 and v['final_loss'] == v['final_loss'], k
+        assert v['steps'] == 50 and v['ms_per_step'] > 0 and v['final_loss'] == v['final_loss'], k
         seq = 512 if 'configs[4]' in k else 256
         assert abs(v['sentences_per_s'] - 64 * seq * 1e3 / v['ms_per_step']) < 1e-6 * v['sentences_per_s']
     assert j['roofline']['kernel'].startswith('gemm_bf16_224_kernel')
