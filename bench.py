@@ -524,7 +524,7 @@ def main():
         if world == 1 and not single_rank_dp and not args.no_other_configs and cfg_label == 'BASELINE configs[1]':
             out.setdefault('extra', {})['other_configs'] = other_configs(device)
         if world == 1 and not single_rank_dp and not args.no_other_configs and cfg_label == 'BASELINE configs[1]':
-            out['extra']['h2d'] = {f'{src}, {w} on the wire': h2d_leg(trainer, args.docs, args.seq, D, D2, device, 20, 5, w, src)
+            out['extra']['h2d'] = {f'{src}, {w} on the wire': h2d_leg(trainer, args.docs, args.seq, D, D2, device, 60, 15, w, src)
                                    for src, w in (('pinned', 'fp32'), ('pageable', 'fp32'), ('pinned', 'bf16'))}
         if world == 1 and not args.no_cpu_baseline and args.arch == 'transformer':
             out['cpu_baseline'] = cpu_baseline(args, D, ff, heads, window, n_layers)
