@@ -390,6 +390,215 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_224r_kernel(const GemmArgs a
   }
 }
 
+// =====================================================================================================================================
+// gemm_variant 8: the same four waves and the same operand paths with the LOOP STRUCTURE of the vendor library's kernel for these shapes
+// (DESIGN.md section 8): ONE LDS stage; every fragment of a K-tile in registers (2 x 8 A + 2 x 7 B); per K-tile
+//   blocks 0..7  (k-step 0): the 15 fragments of k-step 1 are requested two per block;  -> all my reads done, BARRIER 1
+//   blocks 8..12 (k-step 1): the next K-tile goes registers -> LDS, three ds_write_b128 per block, each followed by the global load that
+//                            refills its register with the K-tile after next (ONE register set: a load is in flight for one K-tile);
+//                            -> all my writes done, BARRIER 2
+//   blocks 13..15:           the 15 fragments of the next K-tile's k-step 0 are requested, five per block.
+// Never more than 15 LDS operations of a wave in flight (4-bit lgkmcnt).  Accumulation order as gemm224.hip: bitwise equal results.
+// NT only.
+// =====================================================================================================================================
+template <int KS, int I>
+__device__ __forceinline__ void v_rd_a(s16x8 (&fa)[2][8], unsigned base, const unsigned (&lk)[2]) {
+  const unsigned ad = base + lk[KS];
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[KS][I]) : "v"(ad), "n"(I * 2048));
+}
+template <int N>
+__device__ __forceinline__ void v_block(f32x4 (&acc)[8][7], s16x8 (&fa)[2][8], LFrag<true> (&fb)[2][7]) {
+  constexpr int ks = N >> 3, i = N & 7;
+  asm volatile("" : "+v"(fa[ks][i]));
+  const bf16x8 va = __builtin_bit_cast(bf16x8, fa[ks][i]);
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    asm volatile("" : "+v"(fb[ks][j].k));
+    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[ks][j].k), va, acc[i][j], 0, 0, 0);
+  }
+}
+// request number R (0..14) of a k-step's 15 fragments: 0..6 = B fragment R, 7..14 = A fragment R - 7
+template <int KS, int R>
+__device__ __forceinline__ void v_rd(s16x8 (&fa)[2][8], LFrag<true> (&fb)[2][7], unsigned fA, unsigned fB, const unsigned (&lk)[2]) {
+  if constexpr (R < 7) r_rd_b1<KS, R>(fb[KS], fB, lk);
+  else v_rd_a<KS, R - 7>(fa, fA, lk);
+}
+
+__global__ __launch_bounds__(256, 1) void gemm_bf16_224v_kernel(const GemmArgs a) {
+  constexpr bool B_KMAJOR = true;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave_u >> 1, wn = wave_u & 1;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int ntn = a.N / R_BN, ntm = a.M / 256, nt = ntn * ntm;
+  const int nk = a.K / BK;
+  const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(a.A);
+  const bf16_t* __restrict__ B = reinterpret_cast<const bf16_t*>(a.B);
+  int bm0, bn0;
+  {
+    const int t = blockIdx.x;
+    const int q = nt >> 3, rr = nt & 7, xcd = t & 7, idx = t >> 3;
+    const int id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    if (a.order == 0) { bm0 = (id / ntn) * 256; bn0 = (id % ntn) * R_BN; }
+    else {
+      const int band = id / (4 * ntn), within = id - band * 4 * ntn;
+      const int rows = min(4, ntm - band * 4);
+      bm0 = (band * 4 + within % rows) * 256;
+      bn0 = (within / rows) * R_BN;
+    }
+  }
+  const int ra = tid >> 3, ch = tid & 7;
+  const unsigned voffA = (unsigned)(ra * a.lda + ch * 8) * 2u;
+  const char* baseA = reinterpret_cast<const char*>(A + (size_t)bm0 * a.lda);
+  const unsigned voffB = (unsigned)(ra * a.ldb + ch * 8) * 2u;
+  const char* baseB = reinterpret_cast<const char*>(B + (size_t)bn0 * a.ldb);
+  constexpr int NGB = 7, NW = 15;
+  u32x4 ga[8], gb[NGB];               // ONE register set: K-tile kt + 1 while K-tile kt is multiplied; refilled write by write
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned wA = (unsigned)kmajor_off(ra, ch);
+  unsigned wB[1];
+  wB[0] = R_A_BYTES + (unsigned)kmajor_off(ra, ch);
+  unsigned lk[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) lk[ks] = r16 * 128 + (((ks * 4 + g) ^ ((r16 >> 1) & 7)) << 4);
+  const unsigned fA = lds0 + wm * 16384;
+  const unsigned fB = lds0 + R_A_BYTES + wn * (R_HN * 128);
+
+  s16x8 fa[2][8];
+  LFrag<true> fb[2][7];
+  f32x4 acc[8][7];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 7; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#define VGLOAD(KT, I0_, N_) r_gload<true, I0_, N_, NGB>(ga, gb, baseA + (size_t)(KT) * BK * 2, (size_t)32 * a.lda * 2, baseB + (size_t)(KT) * BK * 2, (size_t)32 * a.ldb * 2, voffA, voffB, voffB)
+#define VBLOCK(N_) do { __builtin_amdgcn_sched_barrier(0); v_block<N_>(acc, fa, fb); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define VRD(KS_, R_) v_rd<KS_, R_>(fa, fb, fA, fB, lk)
+  // ---- prologue: K-tile 0 -> LDS, K-tile 1 -> registers, fragments of K-tile 0 / k-step 0 requested ------------------------------------
+  VGLOAD(0, 0, NW);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  r_lds_write<true, 0, NW, NGB>(lds0, wA, wB, ga, gb);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the writes have read their registers
+  VGLOAD(1, 0, NW);                                       // nk >= 3 (launcher)
+  __builtin_amdgcn_s_barrier();
+  VRD(0, 0); VRD(0, 1); VRD(0, 2); VRD(0, 3); VRD(0, 4); VRD(0, 5); VRD(0, 6); VRD(0, 7); VRD(0, 8); VRD(0, 9); VRD(0, 10); VRD(0, 11); VRD(0, 12);
+  VRD(0, 13); VRD(0, 14);
+
+  // One K-tile.  NXT: K-tile kt + 1 exists (its LDS writes, barrier 2, its first fragment requests); LD: K-tile kt + 2 exists (the refills).
+  auto ktile = [&](int kt, auto NXT, auto LD) {
+    constexpr bool nxt = decltype(NXT)::value, ld = decltype(LD)::value;
+    // k-step 0.  On entry 15 requests are (at most) in flight: B0 x 7, then A0[0..7].  Block n needs B0 and A0[n]: allowed outstanding =
+    // the 7 - n younger A0 requests + the k-step-1 requests issued so far (two per block)
+#define KA(n)                                                               \
+    lgkm_wait<(7 - (n)) + 2 * (n)>();                                       \
+    VBLOCK(n);                                                              \
+    if constexpr (2 * (n) < 15) VRD(1, (2 * (n) < 15 ? 2 * (n) : 0));       \
+    if constexpr (2 * (n) + 1 < 15) VRD(1, (2 * (n) + 1 < 15 ? 2 * (n) + 1 : 0));
+    KA(0) KA(1) KA(2) KA(3) KA(4) KA(5) KA(6) KA(7)
+#undef KA
+    lgkm_wait<0>();                                         // every fragment of this K-tile is in my registers
+    if constexpr (nxt) __builtin_amdgcn_s_barrier();        // ... and in everybody's: the stage may be overwritten
+    // k-step 1: blocks 8..12 carry the next K-tile's 15 writes (3 per block), each write behind the load that filled its register
+    // (in-order vector-memory counter: with refills running, 14 younger loads are allowed; at the end of K only the rest of this set)
+#define KW(w)                                                                                                              \
+    if constexpr (nxt) {                                                                                                   \
+      if constexpr (ld) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");                                                  \
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(14 - (w)) : "memory");                                                 \
+      r_lds_write<true, (w), 1, NGB>(lds0, wA, wB, ga, gb);                                                                \
+      if constexpr (ld) VGLOAD(kt + 2, (w), 1);                                                                            \
+    }
+    VBLOCK(8);  KW(0) KW(1) KW(2)
+    VBLOCK(9);  KW(3) KW(4) KW(5)
+    VBLOCK(10); KW(6) KW(7) KW(8)
+    VBLOCK(11); KW(9) KW(10) KW(11)
+    VBLOCK(12); KW(12) KW(13) KW(14)
+#undef KW
+    if constexpr (nxt) {
+      lgkm_wait<0>();                                       // my writes are in the LDS
+      __builtin_amdgcn_s_barrier();
+    }
+    VBLOCK(13);
+    if constexpr (nxt) { VRD(0, 0); VRD(0, 1); VRD(0, 2); VRD(0, 3); VRD(0, 4); }
+    VBLOCK(14);
+    if constexpr (nxt) { VRD(0, 5); VRD(0, 6); VRD(0, 7); VRD(0, 8); VRD(0, 9); }
+    VBLOCK(15);
+    if constexpr (nxt) { VRD(0, 10); VRD(0, 11); VRD(0, 12); VRD(0, 13); VRD(0, 14); }
+  };
+  {
+    using T = std::true_type; using F = std::false_type;
+    int kt = 0;
+#pragma clang loop unroll(disable)
+    for (; kt + 2 < nk; ++kt) ktile(kt, T{}, T{});
+    ktile(kt, T{}, F{});                                    // kt = nk - 2: writes the last K-tile, no refills
+    ktile(kt + 1, F{}, F{});
+  }
+#undef VGLOAD
+#undef VBLOCK
+#undef VRD
+
+  // ---- epilogue (as gemm_bf16_224r_kernel) ----------------------------------------------------------------------------------------------
+  const int m0 = bm0 + wm * 128, n0 = bn0 + wn * R_HN;
+  __builtin_amdgcn_s_barrier();
+  char* stage = smem + wave_u * 4096;
+  const bool has_bias = (a.epi & MTS_EPI_BIAS) != 0, has_res = (a.epi & MTS_EPI_RESIDUAL) != 0;
+  const float* bias_p = has_bias ? a.bias + n0 + 4 * g : reinterpret_cast<const float*>(a.A) + 4 * g;
+  const size_t res_ld = has_res ? (size_t)a.ldr : 0;
+  const bf16_t* res_p = has_res ? reinterpret_cast<const bf16_t*>(a.residual) + (size_t)(m0 + r16) * a.ldr + n0 + 4 * g
+                                : reinterpret_cast<const bf16_t*>(a.A) + 4 * g;
+  float4 bias[7];
+  uint2 res[8][7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) bias[j] = *reinterpret_cast<const float4*>(bias_p + j * 16);
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 7; ++j) res[i][j] = *reinterpret_cast<const uint2*>(res_p + (size_t)(i * 16) * res_ld + j * 16);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const float colscale = (a.epi & MTS_EPI_COLSCALE) ? a.colscale : 1.0f;
+  const int nsc = (a.epi & MTS_EPI_COLSCALE) ? a.ncols_scaled - n0 - 4 * g : 0;
+  bf16_t* __restrict__ C = reinterpret_cast<bf16_t*>(a.C);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const float sc = (j * 16 < nsc) ? colscale : 1.0f;
+      const float4 bb = has_bias ? bias[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const uint2 rr = has_res ? res[i][j] : make_uint2(0u, 0u);
+      uint2 pk;
+      pk.x = pack_bf16x2((acc[i][j][0] + bb.x) * sc + bf16_lo(rr.x), (acc[i][j][1] + bb.y) * sc + bf16_hi(rr.x));
+      pk.y = pack_bf16x2((acc[i][j][2] + bb.z) * sc + bf16_lo(rr.y), (acc[i][j][3] + bb.w) * sc + bf16_hi(rr.y));
+      *reinterpret_cast<uint2*>(stage + r16 * 240 + (j * 16 + 4 * g) * 2) = pk;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = it * 64 + lane;
+      const int row = idx / 14, chn = idx - row * 14;
+      if (idx < 16 * 14) {
+        const uint4 val = *reinterpret_cast<const uint4*>(stage + row * 240 + chn * 16);
+        *reinterpret_cast<uint4*>(C + (size_t)(m0 + i * 16 + row) * a.ldc + n0 + chn * 8) = val;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+static int v_launch(const GemmArgs& a, hipStream_t st) {
+  auto k = gemm_bf16_224v_kernel;
+  static std::atomic<bool> attr_set{false};
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, R_STAGE);
+    if (e != hipSuccess) { mts_set_error("gemm224v: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MTS_ERR_LAUNCH; }
+    attr_set = true;
+  }
+  const int nt = (a.M / 256) * (a.N / R_BN);
+  hipLaunchKernelGGL(k, dim3(nt), dim3(256), R_STAGE, st, a);
+  return MTS_OK;
+}
+
 template <int LAYOUT, int EXP = 0>
 static int r_launch(const GemmArgs& a, hipStream_t st) {
   auto k = gemm_bf16_224r_kernel<LAYOUT, EXP>;
@@ -415,6 +624,7 @@ int mts_launch_gemm224r(const GemmArgs& a, int layout, bool c_is_f32, int splits
                   (!(a.epi & MTS_EPI_BIAS) || ((uintptr_t)a.bias & 15) == 0) &&
                   (layout == MTS_NT || a.N - 0 >= 32);
   if (!ok) return -1;
+  if (a.variant == 8) return v_launch(a, st);
   if (a.variant == 71) return layout == MTS_NT ? r_launch<MTS_NT, 1>(a, st) : r_launch<MTS_NN, 1>(a, st);
   if (a.variant == 72) return layout == MTS_NT ? r_launch<MTS_NT, 2>(a, st) : r_launch<MTS_NN, 2>(a, st);
   if (a.variant == 73) return layout == MTS_NT ? r_launch<MTS_NT, 3>(a, st) : r_launch<MTS_NN, 3>(a, st);
