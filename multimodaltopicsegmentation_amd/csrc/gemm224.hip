@@ -707,7 +707,7 @@ int mts_launch_gemm224r(const GemmArgs& a, int layout, bool c_is_f32, int splits
 
 // called from mts_gemm (gemm.hip) when N is a multiple of 224 and the 224-wide tiling fills the CUs better
 int mts_launch_gemm224(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st) {
-  if (a.variant == 7 || a.variant == 8 || (a.variant >= 71 && a.variant <= 79)) {                       // A/B: the four-wave register-staged kernel where it applies
+  if (a.variant == 7 || a.variant == 8 || a.variant == 9 || (a.variant >= 71 && a.variant <= 79)) {                       // A/B: the four-wave register-staged kernel where it applies
     const int rc = mts_launch_gemm224r(a, layout, c_is_f32, splits, st);
     if (rc >= 0) return rc;
   }

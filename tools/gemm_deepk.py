@@ -22,7 +22,7 @@ def t(fn):
     return best
 fl = 2.0 * M * N * K / 1e6
 L.check(L.lib.mts_set_option(b'gemm_tile', 224))
-for v in (0, 7, 8):
+for v in (0, 7, 8, 9):
     L.check(L.lib.mts_set_option(b'gemm_variant', v))
     us = t(lambda: ops.gemm(L.NT, A, B, out, M=M, N=N, K=K))
     print(f'gemm_variant {v}: {us:7.1f} us  {fl / us:7.1f} TF/s', flush=True)
