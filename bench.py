@@ -466,13 +466,13 @@ def main():
         # the timed region of a weight-gradient call also holds its split-K reduce kernel (named in the label).
         sym = {(0, 128): 'gemm_bf16_kernel<NT,bf16,GLDS> (128x128)', (1, 128): 'gemm_bf16_kernel<NN,bf16,GLDS> (128x128)',
                (2, 128): 'gemm_bf16_kernel<TN,f32,GLDS> (128x128) + splitk_reduce_kernel',
-               (0, 224): 'gemm_bf16_224_kernel<NT,bf16> (256x224)', (1, 224): 'gemm_bf16_224_kernel<NN,bf16> (256x224)',
+               (0, 224): 'gemm_bf16_224d_kernel<NT,bf16> (256x224, four waves, LDS-DMA)', (1, 224): 'gemm_bf16_224_kernel<NN,bf16> (256x224)',
                (2, 224): 'gemm_bf16_224_kernel<TN,f32> (256x224) + splitk_reduce_kernel',
                (0, 256): 'gemm_bf16_256_kernel<NT,bf16> (256x256)', (1, 256): 'gemm_bf16_256_kernel<NN,bf16> (256x256)',
                (2, 256): 'gemm_bf16_256_kernel<TN,f32> (256x256) + splitk_reduce_kernel'}
         rocprof_names = {(0, 128): ['void gemm_bf16_kernel<0, bool _Accum, bool, E>(GemmArgs)'], (1, 128): ['void gemm_bf16_kernel<1, bool _Accum, bool, E>(GemmArgs)'],
                          (2, 128): ['void gemm_bf16_kernel<2, float, true>(GemmArgs)', 'splitk_reduce_kernel(float const*, int, int, int, float*, int, int)'],
-                         (0, 224): ['_Z20gemm_bf16_224_kernelILi0EDF16bLb0ELb1EEv8GemmArgs'], (1, 224): ['_Z20gemm_bf16_224_kernelILi1EDF16bLb0ELb1EEv8GemmArgs'],
+                         (0, 224): ['gemm_bf16_224d_kernel(GemmArgs)', '_Z20gemm_bf16_224_kernelILi0EDF16bLb0ELb1EEv8GemmArgs'], (1, 224): ['_Z20gemm_bf16_224_kernelILi1EDF16bLb0ELb1EEv8GemmArgs'],
                          (2, 224): ['void gemm_bf16_224_kernel<2, float, true, true>(GemmArgs)', 'splitk_reduce_kernel(float const*, int, int, int, float*, int, int)'],
                          (2, 256): ['void gemm_bf16_256_kernel<2, float, true>(GemmArgs)', 'splitk_reduce_kernel(float const*, int, int, int, float*, int, int)'],
                          (0, 256): ['_Z20gemm_bf16_256_kernelILi0EDF16bLb0EEv8GemmArgs'], (1, 256): ['_Z20gemm_bf16_256_kernelILi1EDF16bLb0EEv8GemmArgs']}

@@ -719,14 +719,23 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_224d_kernel(const GemmArgs a
   const size_t res_ld = has_res ? (size_t)a.ldr : 0;
   const bf16_t* res_p = has_res ? reinterpret_cast<const bf16_t*>(a.residual) + (size_t)(m0 + r16) * a.ldr + n0 + 4 * g
                                 : reinterpret_cast<const bf16_t*>(a.A) + 4 * g;
+  // the bias is wave-uniform work of 7 loads; the residual is 56 loads per lane and a wait of a full memory round trip per tile: only where the
+  // epilogue has one (the forward Q|K|V projection has not: six tiles per CU there)
   float4 bias[7];
   uint2 res[8][7];
 #pragma unroll
   for (int j = 0; j < 7; ++j) bias[j] = *reinterpret_cast<const float4*>(bias_p + j * 16);
+  if (has_res) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 7; ++j) res[i][j] = *reinterpret_cast<const uint2*>(res_p + (size_t)(i * 16) * res_ld + j * 16);
+      for (int j = 0; j < 7; ++j) res[i][j] = *reinterpret_cast<const uint2*>(res_p + (size_t)(i * 16) * res_ld + j * 16);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 7; ++j) res[i][j] = make_uint2(0u, 0u);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const float colscale = (a.epi & MTS_EPI_COLSCALE) ? a.colscale : 1.0f;
   const int nsc = (a.epi & MTS_EPI_COLSCALE) ? a.ncols_scaled - n0 - 4 * g : 0;

@@ -59,7 +59,7 @@ def test_default_line_witnesses_the_other_baseline_configurations():
         assert v['steps'] == 50 and v['ms_per_step'] > 0 and v['final_loss'] == v['final_loss'], k
         seq = 512 if 'configs[4]' in k else 256
         assert abs(v['sentences_per_s'] - 64 * seq * 1e3 / v['ms_per_step']) < 1e-6 * v['sentences_per_s']
-    assert j['roofline']['kernel'].startswith('gemm_bf16_224_kernel')
+    assert j['roofline']['kernel'].startswith('gemm_bf16_224')
 
 
 def _run_env(env, *flags):
