@@ -653,6 +653,13 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_224d_kernel(const GemmArgs a
 #define VBLOCK(N_) do { __builtin_amdgcn_sched_barrier(0); v_block<N_>(acc, fa, fb); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define VRD(ST_, KS_, R_) v_rd<KS_, R_>(fa, fb, fA + (ST_) * R_STAGE, fB + (ST_) * R_STAGE, lk)
 #define CP(C_, KT_, ST_) copy1(std::integral_constant<int, C_>{}, KT_, ST_)
+  // the epilogue's bias (7 x 16 bytes per lane) is fetched HERE, ahead of every copy: after the K loop it cost a memory round trip per tile
+  const int m0 = bm0 + wm * 128, n0 = bn0 + wn * R_HN;
+  const bool has_bias = (a.epi & MTS_EPI_BIAS) != 0, has_res = (a.epi & MTS_EPI_RESIDUAL) != 0;
+  const float* bias_p = has_bias ? a.bias + n0 + 4 * g : reinterpret_cast<const float*>(a.A) + 4 * g;
+  float4 bias[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) bias[j] = *reinterpret_cast<const float4*>(bias_p + j * 16);
   // ---- prologue: K-tiles 0 and 1 -> stages 0 and 1; fragments of K-tile 0 / k-step 0 requested -------------------------------------------
   CP(0, 0, 0); CP(1, 0, 0); CP(2, 0, 0); CP(3, 0, 0); CP(4, 0, 0); CP(5, 0, 0); CP(6, 0, 0); CP(7, 0, 0);
   CP(8, 0, 0); CP(9, 0, 0); CP(10, 0, 0); CP(11, 0, 0); CP(12, 0, 0); CP(13, 0, 0); CP(14, 0, 0);
@@ -711,20 +718,14 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_224d_kernel(const GemmArgs a
 #undef VRD
 
   // ---- epilogue (as gemm_bf16_224r_kernel) ----------------------------------------------------------------------------------------------
-  const int m0 = bm0 + wm * 128, n0 = bn0 + wn * R_HN;
   __builtin_amdgcn_s_barrier();
   char* stage = smem + wave_u * 4096;
-  const bool has_bias = (a.epi & MTS_EPI_BIAS) != 0, has_res = (a.epi & MTS_EPI_RESIDUAL) != 0;
-  const float* bias_p = has_bias ? a.bias + n0 + 4 * g : reinterpret_cast<const float*>(a.A) + 4 * g;
   const size_t res_ld = has_res ? (size_t)a.ldr : 0;
   const bf16_t* res_p = has_res ? reinterpret_cast<const bf16_t*>(a.residual) + (size_t)(m0 + r16) * a.ldr + n0 + 4 * g
                                 : reinterpret_cast<const bf16_t*>(a.A) + 4 * g;
   // the bias is wave-uniform work of 7 loads; the residual is 56 loads per lane and a wait of a full memory round trip per tile: only where the
   // epilogue has one (the forward Q|K|V projection has not: six tiles per CU there)
-  float4 bias[7];
   uint2 res[8][7];
-#pragma unroll
-  for (int j = 0; j < 7; ++j) bias[j] = *reinterpret_cast<const float4*>(bias_p + j * 16);
   if (has_res) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
