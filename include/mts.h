@@ -236,8 +236,8 @@ int mts_band_attn_bwd(void* stream, int dtype, int B, int L, int D, int heads, i
  * Tagger head tail: loss + its gradient, and greedy decode.
  * Replaces: the un-pad loop + BCE/Focal/CE of models/CRF.py:342-356 (=:447-461, :581-595),
  * models/focal_loss.py:38-57, and decode models/CRF.py:362-369.
- * scores: fp32 [B, L, n_out]; targets: fp32 [B, Lt] (pad -1 / 0 as the collater wrote them), Lt >= L;
- * lengths int32 [B].  loss_out: fp32 [2] = {loss, number of rows averaged}.  dscores may be NULL.
+ * scores: fp32 [B, L, n_out] (n_out = 1 for BCE / focal, 2..4 = tagset_size for CrossEntropy); targets: fp32 [B, Lt] (pad -1 / 0 as
+ * the collater wrote them), Lt >= L; lengths int32 [B].  loss_out: fp32 [2] = {loss, number of rows averaged}.  dscores may be NULL.
  * workspace: mts_tagger_loss_workspace(B, L) bytes of device scratch for the per-workgroup partial sums
  * (NULL = single-workgroup path; same result up to fp32 summation order).
  * ------------------------------------------------------------------------------------------- */
@@ -246,10 +246,10 @@ int mts_tagger_loss(void* stream, int loss_kind, int B, int L, int Lt, int n_out
                     const float* targets, const int32_t* lengths, float alpha, float gamma,
                     float* loss_out, float* dscores, void* workspace, size_t workspace_bytes,
                     const int32_t* row_src, int n_rows);
-/* tags_out: uint8 [B, L]; positions >= length are 0.  prob > threshold, strict. */
+/* tags_out: uint8 [B, L]; positions >= length are 0.  prob > threshold, strict; prob = sigmoid (n_out 1) or softmax[..., 1] (n_out 2..4). */
 int mts_greedy_decode(void* stream, int B, int L, int n_out, const float* scores, const int32_t* lengths,
                       float threshold, uint8_t* tags_out);
-/* scores[r, c] = x[r,:] . w[c,:] + b[c]  (x act dtype [rows, D]; w fp32 [n_out, D]); n_out in {1,2,4} */
+/* scores[r, c] = x[r,:] . w[c,:] + b[c]  (x act dtype [rows, D]; w fp32 [n_out, D]); n_out in 1..4 */
 int mts_head_fwd(void* stream, int dtype, int rows, int D, int n_out, const void* x, int ldx, const float* w,
                  const float* b, float* scores);
 /* dw[c,:] = sum_r dscores[r,c] x[r,:], db[c] = sum_r dscores[r,c] (OVERWRITE); workspace as layernorm_bwd */

@@ -704,6 +704,7 @@ static int launch_one(const GemmArgs& a, int splits, hipStream_t st) {
 }
 
 int mts_launch_gemm224r(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st);   // gemm224r.hip: four-wave register-staged form
+int mts_launch_gemm224t(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st);   // gemm224t.hip: four-wave weight-gradient (TN) form
 
 // called from mts_gemm (gemm.hip) when N is a multiple of 224 and the 224-wide tiling fills the CUs better
 int mts_launch_gemm224(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st) {
@@ -713,6 +714,11 @@ int mts_launch_gemm224(const GemmArgs& a, int layout, bool c_is_f32, int splits,
     GemmArgs b = a;
     b.variant = 9;
     const int rc = mts_launch_gemm224r(b, layout, c_is_f32, splits, st);
+    if (rc >= 0) return rc;
+  }
+  // fp32 C, TN (the weight gradients): the four-wave unit-pipelined kernel (gemm224t.hip) where it applies; gemm_variant 6 keeps the eight-wave kernel
+  if (a.variant == 0 && c_is_f32 && layout == MTS_TN) {
+    const int rc = mts_launch_gemm224t(a, layout, c_is_f32, splits, st);
     if (rc >= 0) return rc;
   }
   if (a.variant == 7 || a.variant == 8 || a.variant == 9 || (a.variant >= 71 && a.variant <= 79)) {                       // A/B: the four-wave register-staged kernels where they apply

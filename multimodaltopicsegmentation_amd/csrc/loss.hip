@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void tagger_loss_kernel(int kind, int B, int L
       const int b = in ? src / L : 0, i = in ? src % L : 0;
       y[u] = in ? targets[(size_t)b * Lt + i] : -1.f;
       len[u] = in ? (lengths ? lengths[b] : L) : 0;
-      if (kind == MTS_LOSS_CE) { x0[u] = in ? scores[(size_t)r * 2] : 0.f; x1[u] = in ? scores[(size_t)r * 2 + 1] : 0.f; }
+      if (kind == MTS_LOSS_CE) { x0[u] = (in && n_out == 2) ? scores[(size_t)r * 2] : 0.f; x1[u] = (in && n_out == 2) ? scores[(size_t)r * 2 + 1] : 0.f; }
       else { x0[u] = in ? scores[r] : 0.f; x1[u] = 0.f; }
     }
 #pragma unroll
@@ -98,7 +98,24 @@ __global__ __launch_bounds__(256) void tagger_loss_kernel(int kind, int B, int L
       const int r = base + u * blockDim.x;
       if (r >= N) continue;
       const int i = (row_src ? row_src[r] : r) % L;
-      if (kind == MTS_LOSS_CE) {
+      if (kind == MTS_LOSS_CE && n_out > 2) {
+        // tagset_size 3 or 4 (nn.CrossEntropyLoss over n_out classes, CRF.py:298,354): the general form, straight from memory
+        float xs[4], gs[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < n_out; ++c) xs[c] = scores[(size_t)r * n_out + c];
+        if (y[u] != -1.f) {
+          float m = xs[0];
+          for (int c = 1; c < n_out; ++c) m = fmaxf(m, xs[c]);
+          float se = 0.f;
+          for (int c = 0; c < n_out; ++c) se += expf(xs[c] - m);
+          const float lse = m + logf(se);
+          const int t = (int)y[u];
+          for (int c = 0; c < n_out; ++c) {
+            if (c == t) acc += lse - xs[c];
+            gs[c] = (expf(xs[c] - lse) - (c == t ? 1.f : 0.f)) * inv;
+          }
+        }
+        if (dscores) for (int c = 0; c < n_out; ++c) dscores[(size_t)r * n_out + c] = gs[c];
+      } else if (kind == MTS_LOSS_CE) {
         float g0 = 0.f, g1 = 0.f;
         if (y[u] != -1.f) {
           const float m = fmaxf(x0[u], x1[u]);
@@ -142,7 +159,13 @@ __global__ __launch_bounds__(256) void greedy_decode_kernel(int B, int L, int n_
   const int b = r / L, i = r % L;
   float p;
   if (n_out == 1) p = sigmoid_f(scores[r]);                                   // CRF.py:365
-  else {                                                                      // softmax(...)[..., 1]  CRF.py:367
+  else if (n_out > 2) {                                                       // softmax over 3 or 4 tags, class 1 (CRF.py:367)
+    float m = scores[(size_t)r * n_out];
+    for (int c = 1; c < n_out; ++c) m = fmaxf(m, scores[(size_t)r * n_out + c]);
+    float se = 0.f;
+    for (int c = 0; c < n_out; ++c) se += expf(scores[(size_t)r * n_out + c] - m);
+    p = expf(scores[(size_t)r * n_out + 1] - m) / se;
+  } else {                                                                    // softmax(...)[..., 1]  CRF.py:367
     const float x0 = scores[(size_t)r * 2], x1 = scores[(size_t)r * 2 + 1];
     const float m = fmaxf(x0, x1);
     const float e0 = expf(x0 - m), e1 = expf(x1 - m);
@@ -160,7 +183,7 @@ extern "C" int mts_tagger_loss(void* stream, int loss_kind, int B, int L, int Lt
   MTS_CHECK_ARG(B > 0 && L > 0 && Lt >= L && scores && targets && loss_out, "mts_tagger_loss: bad arguments");
   MTS_CHECK_ARG(loss_kind == MTS_LOSS_CE || loss_kind == MTS_LOSS_BCE || loss_kind == MTS_LOSS_FOCAL,
                 "Choose one of CrossEntropy or BinaryCrossEntropy as loss function");   /* models/CRF.py:312 */
-  MTS_CHECK_ARG((loss_kind == MTS_LOSS_CE) ? n_out == 2 : n_out == 1, "mts_tagger_loss: n_out=%d does not match the loss kind", n_out);
+  MTS_CHECK_ARG((loss_kind == MTS_LOSS_CE) ? (n_out >= 2 && n_out <= 4) : n_out == 1, "mts_tagger_loss: n_out=%d does not match the loss kind", n_out);
   // 256 threads x 8 rows per workgroup; one workgroup (no workspace needed) up to 2048 rows
   MTS_CHECK_ARG(!row_src || (n_rows > 0 && n_rows <= B * L), "mts_tagger_loss: packed form needs 0 < n_rows <= B*L");
   const int nblocks = (int)std::min<size_t>(ceil_div(row_src ? n_rows : B * L, 256 * 2), workspace ? workspace_bytes / sizeof(float) : 1);
@@ -174,7 +197,7 @@ extern "C" int mts_tagger_loss(void* stream, int loss_kind, int B, int L, int Lt
 
 extern "C" int mts_greedy_decode(void* stream, int B, int L, int n_out, const float* scores, const int32_t* lengths, float threshold,
                                  uint8_t* tags_out) {
-  MTS_CHECK_ARG(B > 0 && L > 0 && (n_out == 1 || n_out == 2) && scores && tags_out, "mts_greedy_decode: bad arguments");
+  MTS_CHECK_ARG(B > 0 && L > 0 && n_out >= 1 && n_out <= 4 && scores && tags_out, "mts_greedy_decode: bad arguments");
   hipLaunchKernelGGL(greedy_decode_kernel, dim3(ceil_div(B * L, 256)), dim3(256), 0, (hipStream_t)stream, B, L, n_out, scores, lengths,
                      threshold, tags_out);
   MTS_LAUNCH_CHECK("mts_greedy_decode");

@@ -124,8 +124,10 @@ class _RnnStack:
             S = saved[k]
             din = S['hin'].shape[1]
             w_hh = o._wspan(pf, *self._names('weight_hh', k), 8 * H, H)
-            dxproj = o._ws.get(f'{self.tag}dxproj{k & 1}', N, 8 * H, dt, dev)      # two buffers: layer k's weight gradient may still read its
-                                                                                   # dxproj on the side stream while layer k - 1 fills the other
+            # one buffer PER LAYER: layer k's weight gradient and bias sums read its dxproj on the side stream, and nothing on the main
+            # stream waits for them before the loop ends -- a buffer shared by layers k and k - 2 (two buffers, as this was) is rewritten by
+            # layer k - 2's recurrence with only "a recurrence outlasts a GEMM" in between (silent corruption at >= 3 layers)
+            dxproj = o._ws.get(f'{self.tag}dxproj{k}', N, 8 * H, dt, dev)
             off, n = lay.span(*self._names('weight_hh', k))
             ops.lstm_bwd(w_hh, lengths_i32, S['out'], S['gates'], S['cells'], dout, B, Lq, H, 2, dxproj, g[off:off + n])
             if k > 0:                                                              # the critical path first: what the next recurrence needs

@@ -537,7 +537,9 @@ class Transformer_segmenter(_TaggerBase):
             last = li == len(self.radii) - 1
             head = (self._w(pf, 'classification.weight'), self._w(pf, 'classification.bias'), scores) if last else None
             S = self._band_layer_fwd(self._layer_names(li), str(li), h, lengths_i32, B, Lq, N, radius, row0, pdrop,
-                                     self.dropout_out if self.training else 0.0, head, store_out=need_hidden or not last)
+                                     self.dropout_out if self.training else 0.0, head,
+                                     # (a head wider than two outputs takes its parameter gradients from the stored output: _backward_native)
+                                     store_out=need_hidden or not last or self.n_out > 2)
             st['layers'].append(S)
             h = S['hout']
         st['scores'] = scores if pack else scores.view(B, Lq, self.n_out)

@@ -152,6 +152,39 @@ def test_gemm_224_barrier_schedules_agree_bitwise(ops, layout, M, N, K):
     _close(outs[0][1], ref, 1e-4, 1e-4 * math.sqrt(K), f'{layout} mid-tile barrier fp32 C')
 
 
+@pytest.mark.parametrize('M,N,K,splits', [(256, 224, 128, 1), (256, 224, 192, 1), (512, 448, 256, 1), (768, 224, 1088, 1), (512, 448, 2304, 3), (256, 1792, 2048, 16),
+                                          (1792, 1792, 4096, 4), (5376, 1792, 2048, 0), (2048, 1792, 16384, 0)])
+def test_gemm_224t_matches_the_eight_wave_kernel_bitwise(ops, M, N, K, splits):
+    """Weight gradients (TN, fp32 C): the four-wave unit-pipelined kernel (gemm224t.hip, default) against the eight-wave kernel it replaces
+    (gemm_variant 6) -- same accumulation order per output element, same slices, same fixed-order reduce: identical bits.  Covers the
+    minimum of four units, odd K-tile counts, slices of unequal length, forced and planned K splits, plain and accumulating stores."""
+    from multimodaltopicsegmentation_amd import _lib as L
+    a = _rnd(K, M, seed=71).to(torch.bfloat16).to(DEV)
+    b = _rnd(K, N, seed=72).to(torch.bfloat16).to(DEV)
+    base = _rnd(M, N, seed=73).to(DEV)
+    outs = {}
+    try:
+        L.check(L.lib.mts_set_option(b'gemm_tile', 224))
+        L.check(L.lib.mts_set_option(b'gemm_splits', splits))
+        for variant in (0, 6):
+            L.check(L.lib.mts_set_option(b'gemm_variant', variant))
+            o = torch.full((M, N), float('nan'), dtype=torch.float32, device=DEV)
+            ops.gemm(L.TN, a, b, o, M=M, N=N, K=K)
+            oa = base.clone()
+            ops.gemm(L.TN, a, b, oa, M=M, N=N, K=K, accumulate=True)
+            outs[variant] = (o.clone(), oa.clone())
+    finally:
+        L.check(L.lib.mts_set_option(b'gemm_variant', 0))
+        L.check(L.lib.mts_set_option(b'gemm_splits', 0))
+        L.check(L.lib.mts_set_option(b'gemm_tile', 0))
+    torch.cuda.synchronize()
+    assert not torch.isnan(outs[0][0]).any()
+    ref = a.double().t().cpu() @ b.double().cpu()
+    _close(outs[0][0], ref, 1e-4, 1e-4 * math.sqrt(K), 'TN four-wave fp32 C')
+    for i in range(2):
+        assert torch.equal(outs[0][i].view(torch.int32), outs[6][i].view(torch.int32)), ('plain', 'accumulate')[i]
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_gemm_epilogues(ops, dtype):
     M, N, K = 192, 256, 128

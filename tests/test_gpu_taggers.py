@@ -678,3 +678,74 @@ def test_inference_graph_replay_is_bitwise_the_eager_forward(dtype):
             p.add_(0.01 * torch.randn(p.shape, generator=g).to(DEV))      # weights move (as an optimizer step would)
     s_b = both(x2, l2)
     assert not torch.equal(s_a, s_b)
+
+
+# ------------------------------------------------------------------------------------------------ ADVICE r3
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('tagset', [3, 4])
+def test_transformer_cross_entropy_with_three_and_four_tags_trains(tagset, dtype):
+    """A CrossEntropy head wider than two outputs keeps its own parameter-gradient kernel, which reads the last layer's stored output: the
+    training forward must then store it (`loss().backward()` crashed with AttributeError).  Loss, scores and every gradient against
+    the oracle (models/CRF.py:574-595 with tagset_size 3 / 4)."""
+    from oracle import restatement as R
+    from multimodaltopicsegmentation_amd import TextSegmenter
+    torch.manual_seed(5)
+    D, heads, ff, window, B, Lq = 64, 4, 32, 8, 3, 40
+    ts = TextSegmenter(tagset, D, ff, num_layers=2, architecture='Transformer', loss_fn='CrossEntropy', nheads=heads, attention_window=window,
+                       compute_dtype=dtype).to(DEV)
+    m = ts.model
+    x = torch.randn(B, Lq, D)
+    lengths = torch.tensor([40, 23, 5])
+    y = torch.randint(0, tagset, (B, Lq)).float()
+    for b, n in enumerate(lengths.tolist()):
+        y[b, n:] = -1.0
+    loss = m.loss(x.to(DEV), lengths, y.to(DEV))
+    loss.backward()
+    p = {k: v.detach().double().cpu().requires_grad_(True) for k, v in m.state_dict().items()}
+    ref_scores = R.transformer_scores(x.double(), lengths, p, heads, R.pyramidal_radii(2, window))
+    ref = R.tagger_loss(ref_scores, lengths, y.double(), 'CrossEntropy')
+    ref.backward()
+    f32 = dtype == 'fp32'
+    assert abs(loss.item() - ref.item()) < (2e-6 if f32 else 2e-2) * max(1.0, abs(ref.item())), (loss.item(), ref.item())
+    for n, prm in m.named_parameters():
+        r = p[n].grad
+        if r is None:
+            continue
+        a, r = prm.grad.detach().cpu().double(), r.double()
+        scale = max(float(r.abs().max()), 1e-9)
+        assert float((a - r).abs().max()) < (2e-3 if f32 else 0.1) * scale + (2e-6 if f32 else 3e-3), n
+    scores, tags = m(x.to(DEV), lengths)
+    valid = R.create_mask(Lq, lengths)
+    assert float((scores.cpu().double() - ref_scores.detach())[valid].abs().max()) < (2e-5 if f32 else 5e-2)
+    assert [len(t) for t in tags] == lengths.tolist()
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_three_layer_bilstm_gradients_against_the_oracle(dtype):
+    """num_layers is a CLI argument of the reference (train_fit.py -nlss).  With three layers the side-stream weight gradients of layer 2 and
+    the recurrence of layer 0 used the same dxproj buffer (unsynchronised write-after-read); now one buffer per layer.  H = 256
+    takes the CU-quad recurrences, 20 documents make two document groups."""
+    from oracle import restatement as R
+    from multimodaltopicsegmentation_amd import BiLSTM
+    torch.manual_seed(6)
+    B, Lq, D, Hd, NL = 20, 96, 128, 256, 3
+    m = BiLSTM(2, D, Hd, num_layers=NL, loss_fn='FocalLoss', compute_dtype=dtype, seed=9).to(DEV)
+    x = torch.randn(B, Lq, D)
+    lengths = torch.randint(10, Lq + 1, (B,))
+    lengths[0] = Lq
+    y = (torch.rand(B, Lq) < 0.2).float()
+    for b, n in enumerate(lengths.tolist()):
+        x[b, n:] = 0.0
+        y[b, n:] = -1.0
+    f32 = dtype == 'fp32'
+    p = {k: v.detach().cpu().double().requires_grad_(True) for k, v in m.state_dict().items()}
+    ref = R.tagger_loss(R.bilstm_scores(x.double(), lengths, p, NL, batched=True), lengths, y.double(), 'FocalLoss')
+    ref.backward()
+    for rep in range(3):                               # the race needed a delayed side stream: run it a few times, every run must agree
+        loss, _ = m.loss_and_grad(x.to(DEV), lengths, y.to(DEV), True)
+        torch.cuda.synchronize()
+        assert abs(float(loss) - ref.item()) < (1e-5 if f32 else 2e-2) * max(1.0, abs(ref.item())), (float(loss), ref.item())
+        for n, gv in m.grad_views().items():
+            a, r = gv.detach().cpu().double(), p[n].grad.double()
+            scale = max(float(r.abs().max()), 1e-9)
+            assert float((a - r).abs().max()) < (3e-3 if f32 else 0.1) * scale + (1e-6 if f32 else 2e-4), (rep, n)
