@@ -95,9 +95,11 @@ int mts_gemm_plan(int a_dtype, int c_dtype, int layout, int M, int N, int K, uns
  * the LSTM input projection inside aten::lstm (models/NeuralArchitectures.py:113) and the tagger
  * heads (models/CRF.py:299-310, :554-566); plus their autograd backward.
  * a_dtype: dtype of A and B (and residual/aux); c_dtype: dtype of C (MTS_F32 or a_dtype).
- * workspace (optional, workspace_bytes): scratch for split-K partial tiles of weight-gradient shapes (fp32 C,
- * no epilogue besides MTS_EPI_ACCUM); without it such shapes run unsplit.  Partials are summed in a fixed
- * order, so results are bitwise reproducible.
+ * workspace (optional, workspace_bytes, 16-byte aligned): scratch for split-K partial tiles of weight-gradient shapes
+ * (fp32 C, no epilogue besides MTS_EPI_ACCUM); without it such shapes run unsplit.  bf16 operands: the first 8192 bytes
+ * hold the arrival tickets of the in-launch combine (zeroed by the call itself), the partial planes follow -- a call that
+ * may split K into S slices wants 8192 + S * M * N * 4 bytes.  Partials are summed in slice order whichever slice adds
+ * them (the last one to arrive, inside the launch, or a reduce launch), so results are bitwise reproducible.
  * ------------------------------------------------------------------------------------------- */
 int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int M, int N, int K,
              const void* A, int lda, const void* B, int ldb, void* C, int ldc,

@@ -666,6 +666,7 @@ extern "C" int mts_cast(void* stream, int dst_dtype, const float* src, void* dst
 
 int mts_launch_gemm256(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st);   // gemm256.hip
 int mts_launch_gemm224(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st);   // gemm224.hip
+bool mts_gemm224t_applies(const GemmArgs& a, int layout, bool c_is_f32, int splits);                 // gemm224t.hip
 
 // Tuning / A-B switches and the last-plan record are PER HOST THREAD (include/mts.h "Threads"): mts_set_option from one thread never
 // changes the plan of a GEMM another thread is issuing, and mts_gemm_last_plan reports the calling thread's own most recent call.
@@ -676,6 +677,11 @@ static thread_local int g_tile_order = 1;
 static thread_local int g_gemm_deep = 1;      // "gemm_deep" = 0: never use the four-buffer copy pipeline of the 128x128 kernel (A/B testing)
 static thread_local int g_chain = 0;          // "gemm_chain" = 1: split-K of the 128x128 kernel accumulates in place (no slabs, no reduce launch); measured
                                  // SLOWER (532 vs 465 us on the QKV weight gradient: one agent-scope release per workgroup writes the L2 back)
+static thread_local int g_combine = 0;        // "gemm_combine" = 1: the slice of a tile that arrives last adds the split-K planes of the 256x224 weight-gradient kernel inside
+                                              // the launch (no reduce launch).  Bitwise the same and measured SLOWER (profiles/r04_tn_sweep.txt: 346 vs 276 us on the q|k|v
+                                              // gradient at 3 slices, 164 vs 98 us on the attention-output gradient at 4): 229 KB of fp32 per plane and tile is an order of
+                                              // magnitude past what the guide's recipe pays for, and the agent-scope release of 504 workgroups writes the XCDs' L2s back
+#define MTS_GEMM_WS_HEAD 8192                 // bytes at the start of mts_gemm's workspace reserved for the arrival tickets of the in-launch combine
 static thread_local int g_last_tile = 0, g_last_splits = 0;   // what the planner chose for the most recent bf16 mts_gemm (bench.py labels)
 
 extern "C" int mts_gemm_last_plan(int* tile, int* splits) {
@@ -699,6 +705,7 @@ extern "C" int mts_set_option(const char* key, int value) {
   if (!strcmp(key, "gemm_splits")) { g_force_splits = value; return MTS_OK; }
   if (!strcmp(key, "gemm_order")) { g_tile_order = value; return MTS_OK; }
   if (!strcmp(key, "gemm_chain")) { g_chain = value; return MTS_OK; }
+  if (!strcmp(key, "gemm_combine")) { g_combine = value; return MTS_OK; }
   if (!strcmp(key, "gemm_deep")) { g_gemm_deep = value; return MTS_OK; }
   if (!strcmp(key, "gemm_variant")) { g_gemm_variant = value; return MTS_OK; }
   if (!strcmp(key, "gemm_big_min_k")) { g_big_min_k = value; return MTS_OK; }
@@ -769,7 +776,8 @@ static void plan_bf16(int c_dtype, int layout, int M, int N, int K, unsigned epi
     const int tile = big ? 256 : 128;
     // measured on MI355X (tools/gemm_ksweep.py, gemm_sweep.py): us per K element per round of workgroups, and per-round fixed cost
     const double slots = big ? 256.0 : 512.0;
-    const double t_k = layout == MTS_TN ? (big == 2 ? 0.0200 : big == 1 ? 0.0218 : 0.0145)          // tools/gemm_tn_sweep.py, gemm_ab.py
+    const double t_k = layout == MTS_TN ? (big == 2 ? (M % 256 == 0 ? 0.0160 : 0.0200) : big == 1 ? 0.0218 : 0.0145)   // tools/tn_sweep.py (the four-wave kernel of
+                                                                                                                       // gemm224t.hip takes M % 256 == 0), gemm_ab.py
                                         : (big ? 0.0232 * (big == 2 ? 0.875 : 1.0) : 0.0180);
     const double t_0 = big ? 7.7 : 6.5;
     const int nt = ceil_div(M, tile) * (big == 2 ? N / 224 : ceil_div(N, tile));
@@ -793,7 +801,8 @@ extern "C" int mts_gemm_plan(int a_dtype, int c_dtype, int layout, int M, int N,
   MTS_CHECK_ARG(layout == MTS_NT || layout == MTS_NN || layout == MTS_TN || layout == MTS_TT, "mts_gemm_plan: bad layout %d", layout);
   MTS_CHECK_ARG(a_dtype == MTS_F32 || a_dtype == MTS_BF16, "mts_gemm_plan: bad a_dtype %d", a_dtype);
   int use256 = 0, sp = 1;
-  if (a_dtype == MTS_BF16) plan_bf16(c_dtype, layout, M, N, K, epilogue, workspace_bytes > 0, workspace_bytes, &use256, &sp);
+  const size_t ws_planes = workspace_bytes > MTS_GEMM_WS_HEAD ? workspace_bytes - MTS_GEMM_WS_HEAD : 0;
+  if (a_dtype == MTS_BF16) plan_bf16(c_dtype, layout, M, N, K, epilogue, ws_planes > 0, ws_planes, &use256, &sp);
   if (tile) *tile = a_dtype == MTS_F32 ? (g_f32_mfma ? 128 : 64) : use256 == 2 ? 224 : use256 == 1 ? 256 : 128;
   if (splits) *splits = sp;
   return MTS_OK;
@@ -867,8 +876,11 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
   MTS_UNSUPPORTED(!(epilogue & MTS_EPI_RESIDUAL) || (ldr % 4 == 0 && ((uintptr_t)residual % 8) == 0), "mts_gemm(bf16): residual alignment");
   MTS_UNSUPPORTED(!aux || (ldaux % 4 == 0 && ((uintptr_t)aux % 8) == 0), "mts_gemm(bf16): aux alignment");
 
+  // workspace = [MTS_GEMM_WS_HEAD bytes of arrival tickets][split-K planes]
   int splits = 1, use256 = 0;
-  plan_bf16(c_dtype, layout, M, N, K, epilogue, workspace != nullptr, workspace_bytes, &use256, &splits);
+  const size_t ws_planes = workspace_bytes > MTS_GEMM_WS_HEAD ? workspace_bytes - MTS_GEMM_WS_HEAD : 0;
+  float* const planes = workspace ? (float*)((char*)workspace + MTS_GEMM_WS_HEAD) : nullptr;
+  plan_bf16(c_dtype, layout, M, N, K, epilogue, workspace != nullptr && ws_planes > 0, ws_planes, &use256, &splits);
   g_last_tile = use256 == 2 ? 224 : use256 == 1 ? 256 : 128;
   g_last_splits = splits;
   a.slab = nullptr;
@@ -878,11 +890,18 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
     chained = g_chain && !use256;
     if (chained) {
       const size_t nt128 = (size_t)ceil_div(M, BM) * ceil_div(N, BN);
-      a.chain = (unsigned*)workspace;
-      hipError_t e = hipMemsetAsync(workspace, 0, nt128 * sizeof(unsigned), st);
+      a.chain = (unsigned*)planes;
+      hipError_t e = hipMemsetAsync(planes, 0, nt128 * sizeof(unsigned), st);
       if (e != hipSuccess) { mts_set_error("mts_gemm: hipMemsetAsync: %s", hipGetErrorString(e)); return MTS_ERR_LAUNCH; }
     } else {
-      a.slab = (float*)workspace;
+      a.slab = planes;
+      // weight gradients on the 256x224 four-wave kernel: the slice of a tile that arrives last adds the planes inside the launch
+      // ("gemm_combine" = 0: the reduce launch, A/B); the kernel's launcher falls back to the eight-wave kernel + reduce launch by itself
+      if (use256 == 2 && g_combine && a.variant == 0 && (size_t)ceil_div(M, 256) * (N / 224) * sizeof(unsigned) <= MTS_GEMM_WS_HEAD &&
+          mts_gemm224t_applies(a, layout, c_dtype == MTS_F32, splits)) {
+        a.chain = (unsigned*)workspace;
+        chained = true;
+      }
     }
   }
   if (use256) {
@@ -900,7 +919,7 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
     else launch_bf16<MTS_TN, bf16_t>(a, splits, st);
   }
   if (splits > 1 && !chained)
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((size_t)M * (N / 4) + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((size_t)M * (N / 4) + 255) / 256)), dim3(256), 0, st, (const float*)planes,
                        splits, M, N, (float*)C, ldc, (epilogue & MTS_EPI_ACCUM) ? 1 : 0);
   MTS_LAUNCH_CHECK("mts_gemm(bf16)");
   return MTS_OK;

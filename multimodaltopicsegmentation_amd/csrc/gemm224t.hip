@@ -220,18 +220,61 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_224t_kernel(const GemmArgs a
 #pragma unroll
     for (int j = 0; j < 7; ++j) *reinterpret_cast<float4*>(row + j * 16) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
   }
+  if (!a.slab || !a.chain) return;
+
+  // ---- split-K combine INSIDE the launch: the slice of a tile that arrives last adds the planes, in slice order (what splitk_reduce_kernel
+  // would do in a launch of its own: same order, same bits).  Agent-scope release by every slice, ticket, agent-scope acquire by the last one
+  // (the XCDs' L2s are not coherent with each other; /opt/skills guide, "In-launch split-K reduction"); a.chain[tile] was zeroed by the launcher.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int tile = (bm0 / 256) * ntn + bn0 / T_BN;
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned ticket = __hip_atomic_fetch_add(a.chain + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *reinterpret_cast<volatile __attribute__((address_space(3))) unsigned*>(lds0) = ticket;        // (the one LDS array: no second __shared__ object)
+  }
+  __syncthreads();
+  if (*reinterpret_cast<volatile __attribute__((address_space(3))) unsigned*>(lds0) != (unsigned)(splits - 1)) return;
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  {
+    const size_t plane = (size_t)a.M * a.N;
+    const bool acc_c = (a.epi & MTS_EPI_ACCUM) != 0;
+    float* __restrict__ C = reinterpret_cast<float*>(a.C);
+    // 256 rows x 56 float4: thread t takes float4 number it * 256 + t of the tile (row-major): 56 consecutive threads walk one 896-byte row
+#pragma unroll 2
+    for (int it = 0; it < 56; ++it) {
+      const int idx = it * 256 + tid;
+      const int row = idx / 56, c4 = idx - row * 56;
+      const float* sp = a.slab + (size_t)(bm0 + row) * a.N + bn0 + 4 * c4;
+      float* cp = C + (size_t)(bm0 + row) * a.ldc + bn0 + 4 * c4;
+      float4 s = acc_c ? *reinterpret_cast<const float4*>(cp) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int zz = 0; zz < splits; ++zz) {
+        const float4 v = *reinterpret_cast<const float4*>(sp + (size_t)zz * plane);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      *reinterpret_cast<float4*>(cp) = s;
+    }
+  }
+}
+
+// does this kernel take the call?  (mts_gemm asks before it promises the in-launch combine)
+bool mts_gemm224t_applies(const GemmArgs& a, int layout, bool c_is_f32, int splits) {
+  if (!c_is_f32 || layout != MTS_TN) return false;
+  const int last = a.K - (splits - 1) * a.ksplit;           // k range of the last slice
+  const size_t spanA = ((size_t)a.ksplit + 64) * a.lda * 2, spanB = ((size_t)a.ksplit + 64) * a.ldb * 2;   // byte offsets inside a slice stay below 2^31
+  return (a.epi & ~MTS_EPI_ACCUM) == 0 && (a.M % 256 == 0) && (a.N % T_BN == 0) && (a.K % 64 == 0) && (a.ksplit % 64 == 0) &&
+         a.ksplit >= 128 && last >= 128 && (a.lda % 8 == 0) && (a.ldb % 8 == 0) && (((uintptr_t)a.A & 15) == 0) && (((uintptr_t)a.B & 15) == 0) &&
+         (a.ldc % 4 == 0) && (((uintptr_t)a.C & 15) == 0) && spanA < 0x7ff00000u && spanB < 0x7ff00000u && (splits == 1 || a.slab);
 }
 
 // called from mts_launch_gemm224 (gemm224.hip); -1: shape not covered here
 int mts_launch_gemm224t(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st) {
-  if (!c_is_f32 || layout != MTS_TN) return -1;
-  const int last = a.K - (splits - 1) * a.ksplit;           // k range of the last slice
-  const size_t spanA = ((size_t)a.ksplit + 64) * a.lda * 2, spanB = ((size_t)a.ksplit + 64) * a.ldb * 2;   // byte offsets inside a slice stay below 2^31
-  const bool ok = (a.epi & ~MTS_EPI_ACCUM) == 0 && !a.chain && (a.M % 256 == 0) && (a.N % T_BN == 0) && (a.K % 64 == 0) && (a.ksplit % 64 == 0) &&
-                  a.ksplit >= 128 && last >= 128 && (a.lda % 8 == 0) && (a.ldb % 8 == 0) && (((uintptr_t)a.A & 15) == 0) && (((uintptr_t)a.B & 15) == 0) &&
-                  (a.ldc % 4 == 0) && (((uintptr_t)a.C & 15) == 0) && spanA < 0x7ff00000u && spanB < 0x7ff00000u && (splits == 1 || a.slab) &&
-                  (!(a.epi & MTS_EPI_ACCUM) || splits == 1 || a.slab);
-  if (!ok) return -1;
+  if (!mts_gemm224t_applies(a, layout, c_is_f32, splits)) return -1;
   auto k = gemm_bf16_224t_kernel;
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
@@ -240,6 +283,10 @@ int mts_launch_gemm224t(const GemmArgs& a, int layout, bool c_is_f32, int splits
     attr_set = true;
   }
   const int nt = (a.M / 256) * (a.N / T_BN);
+  if (a.chain) {                                       // the arrival tickets of the in-launch combine: zeroed on the stream, every call
+    hipError_t e = hipMemsetAsync(a.chain, 0, ((size_t)nt * sizeof(unsigned) + 15) & ~(size_t)15, st);
+    if (e != hipSuccess) { mts_set_error("gemm224t: hipMemsetAsync: %s", hipGetErrorString(e)); return MTS_ERR_LAUNCH; }
+  }
   hipLaunchKernelGGL(k, dim3(nt * splits), dim3(256), T_LDS, st, a, splits);
   return MTS_OK;
 }

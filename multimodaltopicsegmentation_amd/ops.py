@@ -102,8 +102,12 @@ def gemm(layout, A, B, out, *, M, N, K, lda=None, ldb=None, ldc=None, bias=None,
     ldc = ldc if ldc is not None else out.stride(0)
     ws, ws_bytes = None, 0
     if layout in (L.TN, L.TT) and c_dt == L.F32 and K >= 2048:
-        ws_bytes = min(16, max(1, K // 1024)) * M * N * 4          # room for up to 16 split-K partial planes
-        ws = _scratch(ws_bytes, A.device, 'splitk')
+        if a_dt == L.BF16:
+            ws_bytes = 8192 + min(16, max(1, K // 1024)) * M * N * 4   # arrival tickets of the in-launch combine + up to 16 split-K partial planes
+        elif -(-M // 128) * -(-N // 128) <= 128:                       # the fp32 kernel only splits K when it has at most 128 output tiles
+            ws_bytes = min(16, 256 // (-(-M // 128) * -(-N // 128)), max(1, K // 512)) * M * N * 4
+        if ws_bytes:
+            ws = _scratch(ws_bytes, A.device, 'splitk')
     key = (layout, a_dt, c_dt, M, N, K)
     with _timed(('gemm', *key, _plan_cache.get(key, 0))):
         check(lib.mts_gemm(stream_ptr(), a_dt, c_dt, layout, M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc, ptr(bias),

@@ -166,15 +166,18 @@ def test_gemm_224t_matches_the_eight_wave_kernel_bitwise(ops, M, N, K, splits):
     try:
         L.check(L.lib.mts_set_option(b'gemm_tile', 224))
         L.check(L.lib.mts_set_option(b'gemm_splits', splits))
-        for variant in (0, 6):
+        for variant, combine in ((0, 1), (0, 0), (6, 1)):      # in-launch combine by the last-arriving slice | reduce launch | the eight-wave kernel
             L.check(L.lib.mts_set_option(b'gemm_variant', variant))
-            o = torch.full((M, N), float('nan'), dtype=torch.float32, device=DEV)
-            ops.gemm(L.TN, a, b, o, M=M, N=N, K=K)
-            oa = base.clone()
-            ops.gemm(L.TN, a, b, oa, M=M, N=N, K=K, accumulate=True)
-            outs[variant] = (o.clone(), oa.clone())
+            L.check(L.lib.mts_set_option(b'gemm_combine', combine))
+            for rep in range(2):                               # twice: the arrival tickets are re-zeroed by every call
+                o = torch.full((M, N), float('nan'), dtype=torch.float32, device=DEV)
+                ops.gemm(L.TN, a, b, o, M=M, N=N, K=K)
+                oa = base.clone()
+                ops.gemm(L.TN, a, b, oa, M=M, N=N, K=K, accumulate=True)
+            outs[variant if combine else 1] = (o.clone(), oa.clone())
     finally:
         L.check(L.lib.mts_set_option(b'gemm_variant', 0))
+        L.check(L.lib.mts_set_option(b'gemm_combine', 1))
         L.check(L.lib.mts_set_option(b'gemm_splits', 0))
         L.check(L.lib.mts_set_option(b'gemm_tile', 0))
     torch.cuda.synchronize()
@@ -183,6 +186,7 @@ def test_gemm_224t_matches_the_eight_wave_kernel_bitwise(ops, M, N, K, splits):
     _close(outs[0][0], ref, 1e-4, 1e-4 * math.sqrt(K), 'TN four-wave fp32 C')
     for i in range(2):
         assert torch.equal(outs[0][i].view(torch.int32), outs[6][i].view(torch.int32)), ('plain', 'accumulate')[i]
+        assert torch.equal(outs[0][i].view(torch.int32), outs[1][i].view(torch.int32)), ('plain', 'accumulate')[i]
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
