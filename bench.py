@@ -113,12 +113,12 @@ def cpu_baseline(args, D, ff, heads, window, n_layers):
               f'({best:.2f} s/step); threads picked from {cands} by a probe on {min(8, args.cpu_docs)} docs '
               f'({", ".join(f"{t}: {v:.2f} s" for t, v in timing.items())})')
     try:
-        rv = json.load(open(os.path.join(ROOT, 'profiles', 'r02_cpu_ref_vs_port.json')))
+        rv = json.load(open(os.path.join(ROOT, 'profiles', 'r04_cpu_ref_vs_port.json')))
         sample += (f'; port vs the reference itself, measured in the build container ({rv["sample"]}, {rv["threads"]} threads, '
                    f'tools/cpu_ref_vs_port.py): reference {rv["reference_sentences_per_s"]:.0f} sentences/s, this port '
                    f'{rv["port_blocked_sentences_per_s"]:.0f} = {rv["port_blocked_vs_reference"]:.2f}x the reference')
     except (OSError, ValueError, KeyError):
-        sample += '; port-vs-reference ratio: profiles/r02_cpu_ref_vs_port.json missing'
+        sample += '; port-vs-reference ratio: profiles/r04_cpu_ref_vs_port.json missing'
     return {'value': args.cpu_docs * args.seq / best, 'unit': 'sentences/s', 'cores': cores, 'kind': 'port', 'sample': sample}
 
 
@@ -191,6 +191,8 @@ def h2d_leg(trainer, docs, seq, D, D2, device, steps, warmup, wire='fp32', sourc
     buffers) -> the leg measures how well the PCIe transfer hides under the step; 'pageable': the prefetcher's producer thread also
     stages every batch into its pinned ring (one host memcpy of the batch per step).  Never part of `value`."""
     from multimodaltopicsegmentation_amd.prefetch import DevicePrefetcher
+    if source == 'collater':
+        return h2d_collater_leg(trainer, docs, seq, D, D2, device, steps, warmup, wire)
     host = []
     for i in range(3):
         b = synthetic_batch(docs, seq, D, 100 + i, 'cpu', D2)
@@ -221,6 +223,48 @@ def h2d_leg(trainer, docs, seq, D, D2, device, steps, warmup, wire='fp32', sourc
             'wire_dtype': wire + (' (the host batches already hold bf16 embeddings)' if wire == 'bf16' else ''), 'host_memory': source, 'MB_per_batch': per_batch / 1e6,
             'pcie_GBps_sustained': per_batch * steps / dt / 1e9,
             'note': 'host batches -> DevicePrefetcher (side-stream H2D two batches ahead) -> step; NOT the headline value'}
+
+
+def h2d_collater_leg(trainer, docs, seq, D, D2, device, steps, warmup, wire):
+    """documents -> the PRODUCT's collater -> DevicePrefetcher -> step: a synthetic corpus of 4 x `docs` documents held on the host,
+    `AudioPortionDataset(pin_memory=True, wire_dtype=wire)` pads every batch into its pinned ring (mts_collate_pad, one threaded pass;
+    wire = 'bf16': the corpus is converted once, when the dataset is built), the prefetcher sends the collater's own buffers.  The
+    collation runs inside the timed loop, on the prefetcher's producer thread.  Never part of `value`."""
+    from multimodaltopicsegmentation_amd.encoder_dataset import AudioPortionDataset
+    from multimodaltopicsegmentation_amd.prefetch import DevicePrefetcher
+    g = torch.Generator().manual_seed(4321)
+    n_docs = 4 * docs
+    lines = [(torch.randn(seq, D, generator=g), (torch.rand(seq, generator=g) < 0.05).float().tolist(), f'doc{i}') for i in range(n_docs)]
+    second = [(torch.randn(seq, D2, generator=g), None, f'doc{i}') for i in range(n_docs)] if D2 else None
+    threads = min(16, os.cpu_count() or 8)
+    ds = AudioPortionDataset(lines, {'0': 0, '1': 1}, CRF=False, truncate=False, second_input=second, pin_memory=True, wire_dtype=wire,
+                             pin_slots=4, collate_threads=threads)
+    n_total = warmup + steps
+    t_collate = [0.0, 0]
+
+    def batches():
+        for i in range(n_total):
+            idx = [(i * docs + j) % n_docs for j in range(docs)]
+            t0 = time.perf_counter()
+            b = ds.collater(ds.__getitems__(idx))         # the batched fetch a torch DataLoader makes (encoder_dataset.py: indices -> fast path)
+            t_collate[0] += time.perf_counter() - t0
+            t_collate[1] += 1
+            yield b
+    pf = DevicePrefetcher(batches(), device, depth=2)
+    t0 = None
+    for i, batch in enumerate(pf):
+        if i == warmup:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        trainer.step(batch)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    per_batch = docs * seq * ((D + (D2 or 0)) * (2 if wire == 'bf16' else 4) + 4)
+    return {'ms_per_step': 1e3 * dt / steps, 'sentences_per_s': docs * seq * steps / dt, 'steps': steps, 'warmup': warmup,
+            'wire_dtype': wire + (' (the corpus is held in bf16 on the host)' if wire == 'bf16' else ''), 'host_memory': 'the collater\'s pinned ring',
+            'MB_per_batch': per_batch / 1e6, 'pcie_GBps_sustained': per_batch * steps / dt / 1e9,
+            'collater_ms_per_batch': 1e3 * t_collate[0] / max(1, t_collate[1]), 'collate_threads': threads,
+            'note': 'documents -> AudioPortionDataset(pin_memory=True).collater -> DevicePrefetcher -> step; NOT the headline value'}
 
 
 def self_launch(n, rehearsal):
@@ -265,7 +309,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--cpu-docs', type=int, default=32)
     ap.add_argument('--sustained-steps', type=int, default=1000, help='extra timed leg after the K-step region (0 = skip); reported under "extra"')
-    ap.add_argument('--h2d', default=None, choices=['pinned', 'pageable'], help='variant line: host batches through prefetch.DevicePrefetcher '
+    ap.add_argument('--h2d', default=None, choices=['pinned', 'pageable', 'collater'], help='variant line: host batches through prefetch.DevicePrefetcher '
                     'in the loop (PCIe-inclusive step); the batches live in pinned or pageable host memory')
     ap.add_argument('--h2d-wire', default='fp32', choices=['fp32', 'bf16'], help='--h2d: dtype of the embeddings on the wire')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -520,12 +564,12 @@ def main():
                 gbs = by / (other['band_fwd']['avg_us'] * 1e-6) / 1e9
                 out['kernels']['band_attn_fwd'] = {**other['band_fwd'], 'algorithmic_GBps': gbs, 'hbm_frac': gbs / HBM_PEAK_GBS}
             if 'band_bwd' in wother:
-                out['kernels']['band_attn_bwd (2 launches)'] = wother['band_bwd']
+                out['kernels']['band_attn_bwd (one pass)'] = wother['band_bwd']
         if world == 1 and not single_rank_dp and not args.no_other_configs and cfg_label == 'BASELINE configs[1]':
             out.setdefault('extra', {})['other_configs'] = other_configs(device)
         if world == 1 and not single_rank_dp and not args.no_other_configs and cfg_label == 'BASELINE configs[1]':
             out['extra']['h2d'] = {f'{src}, {w} on the wire': h2d_leg(trainer, args.docs, args.seq, D, D2, device, 60, 15, w, src)
-                                   for src, w in (('pinned', 'fp32'), ('pageable', 'fp32'), ('pinned', 'bf16'))}
+                                   for src, w in (('pinned', 'fp32'), ('pageable', 'fp32'), ('pinned', 'bf16'), ('collater', 'fp32'), ('collater', 'bf16'))}
         if world == 1 and not args.no_cpu_baseline and args.arch == 'transformer':
             out['cpu_baseline'] = cpu_baseline(args, D, ff, heads, window, n_layers)
         print(json.dumps(out))

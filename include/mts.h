@@ -119,6 +119,14 @@ int mts_cast(void* stream, int dst_dtype, const float* src, void* dst, size_t n)
  * (src1 [rows, D1] | src2 [rows, D2], D1 and D2 multiples of 4) so that the concatenated batch never exists: dst [rows, D1+D2] in the
  * act dtype for the recurrent taggers' first projection ... */
 int mts_cast_concat(void* stream, int dst_dtype, size_t rows, int D1, int D2, const float* src1, const float* src2, void* dst);
+/* HOST-SIDE COLLATION (no device call, no stream).  Replaces the `merge` closure of AudioPortionDataset.collater (EncoderDataset.py:20-27,
+ * :103-109): B ragged documents docs[b] = [doc_rows[b], D] (src_dtype MTS_F32 | MTS_BF16, row-major, contiguous) -> dst [B, Lmax, D] in
+ * dst_dtype, rows past min(doc_rows[b], Lmax) = pad_value (0 for the embeddings, -1 / 0 for the targets: EncoderDataset.py:23; the
+ * reference's truncate = "pad / cut to exactly Lmax").  The one pass that pads also
+ * narrows fp32 -> bf16 (round to nearest even) where the dtypes differ, and is split over `nthreads` host threads (a persistent pool inside the library).  dst may be pinned
+ * memory: the batch is then ready for an asynchronous host-to-device copy as it stands (prefetch.DevicePrefetcher sends it unstaged). */
+int mts_collate_pad(int src_dtype, int dst_dtype, int B, int Lmax, int D, const void* const* docs, const int64_t* doc_rows, void* dst,
+                    float pad_value, int nthreads);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm family (biased variance, eps inside sqrt).

@@ -10,9 +10,17 @@ import os
 # once RCCL's own streams exist in the process (any N > 1 run) two of ours share a hardware queue and the encoders run one after
 # the other: 13.3 ms per step instead of 7.7 at 64 x 512 (measured with a one-rank RCCL group, profiles/r03_hw_queues.txt).
 # Eight queues restore the overlap.  Only effective if set before the HIP runtime initialises, hence here, at import.
+_HWQ_PRESET = 'GPU_MAX_HW_QUEUES' in os.environ
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 import torch
+
+if not _HWQ_PRESET and torch.cuda.is_initialized():
+    # the HIP runtime read its environment before this import: the default of four hardware queues stays for this process
+    import warnings
+    warnings.warn('multimodaltopicsegmentation_amd was imported after the GPU runtime had been initialised: GPU_MAX_HW_QUEUES=8 could not '
+                  'take effect (the late-fusion tagger\'s two encoder streams may share a hardware queue next to RCCL: 13.3 instead of 7.7 ms '
+                  'per step at 64 x 512).  Import the package first, or export GPU_MAX_HW_QUEUES=8.', RuntimeWarning, stacklevel=2)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libmts_hip.so')
@@ -79,6 +87,7 @@ SIGNATURES = {
     'mts_adam_step': (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i, _f, _vp]),
     'mts_sgd_step': (_i, [_vp, _sz, _vp, _vp, _vp, _f, _f, _f, _i, _f, _vp]),
     'mts_scale': (_i, [_vp, _sz, _vp, _f]),
+    'mts_collate_pad': (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i]),
 }
 
 _missing = []

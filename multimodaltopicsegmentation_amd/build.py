@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libmts_hip.so')
-SOURCES = ['gemm.hip', 'gemm256.hip', 'gemm224.hip', 'gemm224r.hip', 'gemm224t.hip', 'ffn_fused.hip', 'norm.hip', 'band_attn.hip', 'band_attn_mfma.hip', 'loss.hip', 'dropout.hip', 'optim.hip', 'lstm.hip', 'lstm_mfma.hip', 'lstm_pair.hip', 'crf.hip']
+SOURCES = ['gemm.hip', 'gemm256.hip', 'gemm224.hip', 'gemm224r.hip', 'gemm224t.hip', 'ffn_fused.hip', 'norm.hip', 'band_attn.hip', 'band_attn_mfma.hip', 'loss.hip', 'dropout.hip', 'optim.hip', 'lstm.hip', 'lstm_mfma.hip', 'lstm_pair.hip', 'crf.hip', 'collate.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wno-unused-result']
 
 
@@ -43,7 +43,7 @@ def build(force=False, verbose=True):
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(_compile, srcs))
     if any(_newer(o, LIB) for o in objs):
-        cmd = ['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB, *objs]
+        cmd = ['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-pthread', '-o', LIB, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('link failed:\n%s\n%s' % (r.stdout, r.stderr))

@@ -20,8 +20,7 @@ __device__ __forceinline__ float lse_arr(const float* v, int n) {
 // ------------------------------------------------------------------------------------------------
 // C == 4 (binary tagset + START/STOP: every configuration of the reference): one QUAD of lanes per document, lane i
 // owns tag i.  The C x C table lives in 8 registers per lane (its row and its column), the alpha/beta vectors are
-// exchanged with DPP quad broadcasts, so a step is ~4 exp + 1 log per lane with no memory on the dependent chain except the
-// (prefetchable) emission row.  Same association of the additions as the generic kernel below.
+// exchanged with DPP quad broadcasts, no memory on the dependent chain except the (prefetched) emission row.
 // ------------------------------------------------------------------------------------------------
 template <int J> __device__ __forceinline__ float quad_bcast(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), J * 0x55, 0xf, 0xf, false));
@@ -32,6 +31,20 @@ __device__ __forceinline__ float lse4(float v0, float v1, float v2, float v3) {
   return m + logf(s);
 }
 
+// Forward-backward in the SCALED PROBABILITY domain.  The first version of this kernel walked the log domain: four expf and a logf on every
+// forward step, five expf and an lse4 on every backward step, ~250 instructions per step of a lone wave -- 299 us per training step at
+// 64 x 256 (8 % of the BiLSTM + CRF step).  With p_t = softmax(alpha_t) carried instead of alpha_t (the textbook scaled recursion):
+//     u_i = (sum_j exp(T[i][j]) p_t(j)) * e_t(i),  e_t(i) = exp(f_t(i) - max_i f_t(i));   z_t = sum_i u_i;   p_{t+1} = u / z_t
+//     log Z = sum_t (log z_t + max_i f_t(i)) + log(sum_i p_n(i) exp(T[stop][i]))
+//     bhat_n(i) = exp(T[stop][i]) / sum_i p_n(i) exp(T[stop][i]);   bhat_t(j) = sum_i exp(T[i][j]) e_t(i) bhat_{t+1}(i) / z_t
+//     P(y_t = i) = p_{t+1}(i) bhat_{t+1}(i);   P(y_{t-1} = j, y_t = i) = p_t(j) exp(T[i][j]) e_t(i) bhat_{t+1}(i) / z_t
+// a step is four multiply-adds, one exp2 of the emission row (independent of the recursion), a quad sum and a reciprocal: ~50 instructions.
+// exp(-1e4) is exactly 0, as it is (after the max shift) in the log-domain sums: IMPOSSIBLE transitions behave as before.  Same results to
+// fp32 rounding (tests/test_gpu_kernels.py::test_crf_nll_viterbi, ::test_crf_long_documents; fixture g5).  The saved state is p_t (in the
+// `alphas` buffer); z_t is recomputed from it in the reverse sweep.
+__device__ __forceinline__ float quad_sum(float v) { return (quad_bcast<0>(v) + quad_bcast<1>(v)) + (quad_bcast<2>(v) + quad_bcast<3>(v)); }
+__device__ __forceinline__ float quad_max(float v) { return fmaxf(fmaxf(quad_bcast<0>(v), quad_bcast<1>(v)), fmaxf(quad_bcast<2>(v), quad_bcast<3>(v))); }
+
 __global__ __launch_bounds__(64) void crf_nll4_kernel(int B, int L, const float* __restrict__ feats, const float* __restrict__ tags, int Lt,
                                                       const int32_t* __restrict__ lengths, const float* __restrict__ trans,
                                                       float* __restrict__ dfeats, float* __restrict__ alphas, float* __restrict__ part) {
@@ -40,26 +53,36 @@ __global__ __launch_bounds__(64) void crf_nll4_kernel(int B, int L, const float*
   const int b = blockIdx.x * 16 + (threadIdx.x >> 2);
   if (b >= B) return;                                   // whole quads leave together
   const int n = lengths ? max(min(lengths[b], L), 0) : L;
-  float Tr[4], Tc[4];
+  float Er[4], Ec[4];                                   // exp of my row (to me from j) and my column (from me to j) of the transition table
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { Tr[j] = trans[i * C + j]; Tc[j] = trans[j * C + i]; }
-  const float Tstop = trans[stop * C + i];
+  for (int j = 0; j < 4; ++j) { Er[j] = expf(trans[i * C + j]); Ec[j] = expf(trans[j * C + i]); }
+  const float Estop = expf(trans[stop * C + i]);
   const float* f = feats + (size_t)b * L * C;
   float* al = alphas + (size_t)b * (L + 1) * C;
   const float* tg = tags + (size_t)b * Lt;
-  float a = (i == start) ? 0.f : CRF_IMPOSSIBLE;
-  al[i] = a;
-  float fn = n > 0 ? f[i] : 0.f;
+  float p = (i == start) ? 1.f : 0.f;
+  al[i] = p;
+  float logscale = 0.f;
+  float fq[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) fq[d] = d < n ? f[d * C + i] : 0.f;
   for (int t = 0; t < n; ++t) {
-    const float ft = fn;
-    if (t + 1 < n) fn = f[(t + 1) * C + i];              // next emission row in flight behind this step's exp/log
-    const float v0 = quad_bcast<0>(a) + Tr[0] + ft, v1 = quad_bcast<1>(a) + Tr[1] + ft;
-    const float v2 = quad_bcast<2>(a) + Tr[2] + ft, v3 = quad_bcast<3>(a) + Tr[3] + ft;
-    a = lse4(v0, v1, v2, v3);
-    al[(t + 1) * C + i] = a;
+    const float ft = fq[0];
+    fq[0] = fq[1]; fq[1] = fq[2]; fq[2] = fq[3];
+    fq[3] = (t + 4 < n) ? f[(t + 4) * C + i] : 0.f;      // emission rows four steps ahead
+    const float sgm = ((Er[0] * quad_bcast<0>(p) + Er[1] * quad_bcast<1>(p)) + Er[2] * quad_bcast<2>(p)) + Er[3] * quad_bcast<3>(p);
+    // the shift is the largest emission among the REACHABLE tags (a tag nobody can move to -- START -- may carry the row's maximum: shifted
+    // by it every reachable term could underflow and z with them)
+    const float m = quad_max(sgm > 0.f ? ft : -INFINITY);
+    const float e = sgm > 0.f ? expf(ft - m) : 0.f;
+    const float u = sgm * e;
+    const float z = quad_sum(u);
+    p = u / z;
+    logscale += logf(z) + m;
+    al[(t + 1) * C + i] = p;
   }
-  const float vs = a + Tstop;
-  const float logZ = lse4(quad_bcast<0>(vs), quad_bcast<1>(vs), quad_bcast<2>(vs), quad_bcast<3>(vs));
+  const float zn = quad_sum(p * Estop);
+  const float logZ = logscale + logf(zn);
   // gold path score (CRF.py:148-170): the 4 lanes take every 4th step, combined in a fixed order
   float gpart = 0.f;
   for (int t = i; t < n; t += 4) {
@@ -71,28 +94,36 @@ __global__ __launch_bounds__(64) void crf_nll4_kernel(int B, int L, const float*
   float* pp = part + (size_t)b * (C * C + 1);
   if (i == 0) pp[C * C] = logZ - gold;
   if (!dfeats) return;
-  // reverse sweep: beta recursion -> marginals; the gold path's one-hot counts are subtracted on the fly
+  // reverse sweep: scaled beta recursion -> marginals; the gold path's one-hot counts are subtracted on the fly
   float dT[4] = {0.f, 0.f, 0.f, 0.f};
-  const float dstop = expf(a + Tstop - logZ);            // P(last tag = i): row `stop`, column i
-  float beta = Tstop;
+  float bh = Estop / zn;                                 // bhat_n(i)
+  const float dstop = p * bh;                            // P(last tag = i): row `stop`, column i
   float* df = dfeats + (size_t)b * L * C;
+  // operands of step t: emission row, p_t and p_{t+1}, the gold tags -- requested two steps ahead
+  float f0 = n > 0 ? f[(n - 1) * C + i] : 0.f, f1 = n > 1 ? f[(n - 2) * C + i] : 0.f;
+  float a0 = n > 0 ? al[(n - 1) * C + i] : 0.f, a1 = n > 1 ? al[(n - 2) * C + i] : 0.f;
+  float pnext = p;                                       // p_{t+1}
   for (int t = n - 1; t >= 0; --t) {
-    const float ft = f[t * C + i], anext = al[(t + 1) * C + i], aprev = al[t * C + i];
+    const float ft = f0, pt = a0;
+    f0 = f1; a0 = a1;
+    if (t >= 2) { f1 = f[(t - 2) * C + i]; a1 = al[(t - 2) * C + i]; }
     const int y = (int)tg[t], prev = t > 0 ? (int)tg[t - 1] : start;
-    float marg = expf(anext + beta - logZ);
-    const float ap0 = quad_bcast<0>(aprev), ap1 = quad_bcast<1>(aprev), ap2 = quad_bcast<2>(aprev), ap3 = quad_bcast<3>(aprev);
-    dT[0] += expf(ap0 + Tr[0] + ft + beta - logZ);
-    dT[1] += expf(ap1 + Tr[1] + ft + beta - logZ);
-    dT[2] += expf(ap2 + Tr[2] + ft + beta - logZ);
-    dT[3] += expf(ap3 + Tr[3] + ft + beta - logZ);
+    const float p0 = quad_bcast<0>(pt), p1 = quad_bcast<1>(pt), p2 = quad_bcast<2>(pt), p3 = quad_bcast<3>(pt);
+    const float sgm = ((Er[0] * p0 + Er[1] * p1) + Er[2] * p2) + Er[3] * p3;
+    const float m = quad_max(sgm > 0.f ? ft : -INFINITY);       // (the forward step's own arithmetic: the same z, bit for bit)
+    const float e = sgm > 0.f ? expf(ft - m) : 0.f;
+    const float z = quad_sum(sgm * e);
+    const float w = e * bh / z;                          // e_t(i) bhat_{t+1}(i) / z_t
+    float marg = pnext * bh;
+    dT[0] += p0 * Er[0] * w; dT[1] += p1 * Er[1] * w; dT[2] += p2 * Er[2] * w; dT[3] += p3 * Er[3] * w;
     if (y == i) {
       marg -= 1.f;
       dT[0] -= (prev == 0) ? 1.f : 0.f; dT[1] -= (prev == 1) ? 1.f : 0.f; dT[2] -= (prev == 2) ? 1.f : 0.f; dT[3] -= (prev == 3) ? 1.f : 0.f;
     }
-    const float nb = lse4(Tc[0] + quad_bcast<0>(ft) + quad_bcast<0>(beta), Tc[1] + quad_bcast<1>(ft) + quad_bcast<1>(beta),
-                          Tc[2] + quad_bcast<2>(ft) + quad_bcast<2>(beta), Tc[3] + quad_bcast<3>(ft) + quad_bcast<3>(beta));
     df[t * C + i] = marg;
-    beta = nb;
+    // bhat = (smoothed / filtered probability of the tag): finite whenever the filtered one is not 0; the clamp keeps 0 * bhat = 0 there
+    bh = fminf(((Ec[0] * quad_bcast<0>(w) + Ec[1] * quad_bcast<1>(w)) + Ec[2] * quad_bcast<2>(w)) + Ec[3] * quad_bcast<3>(w), 1e30f);
+    pnext = pt;
   }
   for (int t = n; t < L; ++t) df[t * C + i] = 0.f;
   const float ds0 = quad_bcast<0>(dstop), ds1 = quad_bcast<1>(dstop), ds2 = quad_bcast<2>(dstop), ds3 = quad_bcast<3>(dstop);
@@ -104,10 +135,14 @@ __global__ __launch_bounds__(64) void crf_nll4_kernel(int B, int L, const float*
   for (int j = 0; j < 4; ++j) pp[i * C + j] = dT[j];
 }
 
-// Viterbi for C == 4: back-pointers stay in LDS (one byte each), the back-trace is walked by the quad's first lane
+// Viterbi for C == 4: the back-pointers stay in LDS, the back-trace is walked by the quad's first lane.  A step's four back-pointers are
+// two bits each and share ONE byte (the quad ORs its lanes' fields together with DPP broadcasts, lane 0 stores it): 16 documents x L bytes, so
+// a block of full-length documents fits the LDS up to L = 10 240 -- with a byte per pointer (the first version) a single 2 437-sentence
+// document (predict.py: one document per call) needed 156 KB for its block, and the call fell back to the generic kernel below: one lane, four
+// dependent global stores per step, 5.7 ms per document.
 __global__ __launch_bounds__(64) void crf_viterbi4_kernel(int B, int L, const float* __restrict__ feats, const int32_t* __restrict__ lengths,
                                                           const float* __restrict__ trans, float* __restrict__ best_score, int32_t* __restrict__ paths) {
-  extern __shared__ unsigned char bp_lds[];            // [16 documents][L][4]
+  extern __shared__ unsigned char bp_lds[];            // [16 documents][L]
   constexpr int C = 4, start = 2, stop = 3;
   const int i = threadIdx.x & 3, q = threadIdx.x >> 2;
   const int b = blockIdx.x * 16 + q;
@@ -117,18 +152,26 @@ __global__ __launch_bounds__(64) void crf_viterbi4_kernel(int B, int L, const fl
 #pragma unroll
   for (int j = 0; j < 4; ++j) Tr[j] = trans[i * C + j];
   const float* f = feats + (size_t)b * L * C;
-  unsigned char* bp = bp_lds + (size_t)q * L * C;
+  unsigned char* bp = bp_lds + (size_t)q * L;
   float m = (i == start) ? 0.f : CRF_IMPOSSIBLE;
-  float fn = n > 0 ? f[i] : 0.f;
+  // emission rows four steps ahead of the step that needs them: the row is the only memory operand of a step, and a load issued one step
+  // ahead (a step is ~20 instructions) had not landed when the step wanted it
+  float fq[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) fq[d] = d < n ? f[d * C + i] : 0.f;
   for (int t = 0; t < n; ++t) {
-    const float ft = fn;
-    if (t + 1 < n) fn = f[(t + 1) * C + i];
+    const float ft = fq[0];
+    fq[0] = fq[1]; fq[1] = fq[2]; fq[2] = fq[3];
+    fq[3] = (t + 4 < n) ? f[(t + 4) * C + i] : 0.f;
     float best = quad_bcast<0>(m) + Tr[0];
     int arg = 0;
     float v = quad_bcast<1>(m) + Tr[1]; if (v > best) { best = v; arg = 1; }
     v = quad_bcast<2>(m) + Tr[2]; if (v > best) { best = v; arg = 2; }
     v = quad_bcast<3>(m) + Tr[3]; if (v > best) { best = v; arg = 3; }
-    bp[t * C + i] = (unsigned char)arg;
+    const int fld = arg << (2 * i);
+    const int packed = (__builtin_amdgcn_update_dpp(0, fld, 0 * 0x55, 0xf, 0xf, false) | __builtin_amdgcn_update_dpp(0, fld, 1 * 0x55, 0xf, 0xf, false)) |
+                       (__builtin_amdgcn_update_dpp(0, fld, 2 * 0x55, 0xf, 0xf, false) | __builtin_amdgcn_update_dpp(0, fld, 3 * 0x55, 0xf, 0xf, false));
+    if (i == 0) bp[t] = (unsigned char)packed;
     m = best + ft;
   }
   const float vs = m + trans[stop * C + i];
@@ -145,7 +188,7 @@ __global__ __launch_bounds__(64) void crf_viterbi4_kernel(int B, int L, const fl
     best_score[b] = best;
     for (int t = n - 1; t >= 0; --t) {
       p[t] = tag;
-      tag = bp[t * C + tag];
+      tag = (bp[t] >> (2 * tag)) & 3;
     }
   }
 }
@@ -317,8 +360,17 @@ extern "C" int mts_crf_viterbi(void* stream, int B, int L, int C, const float* f
                                float* best_score, int32_t* paths, int32_t* bp_ws) {
   MTS_CHECK_ARG(B > 0 && L > 0 && C >= 3 && C <= CRF_MAXC, "mts_crf_viterbi: bad shape (C must be in 3..8)");
   MTS_CHECK_ARG(feats && trans && best_score && paths && bp_ws, "mts_crf_viterbi: null pointer");
-  if (C == 4 && (size_t)16 * L * 4 <= 64 * 1024)
-    hipLaunchKernelGGL(crf_viterbi4_kernel, dim3(ceil_div(B, 16)), dim3(64), (size_t)16 * L * 4, (hipStream_t)stream, B, L, feats, lengths, trans, best_score,
+  const size_t bp_bytes = (size_t)16 * L;                   // one byte per document and step (four 2-bit back-pointers)
+  bool quad = C == 4 && bp_bytes <= 160 * 1024;
+  if (quad && bp_bytes > 64 * 1024) {
+    static std::atomic<bool> attr{false};
+    if (!attr) {
+      if (hipFuncSetAttribute((const void*)crf_viterbi4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) quad = false;
+      else attr = true;
+    }
+  }
+  if (quad)
+    hipLaunchKernelGGL(crf_viterbi4_kernel, dim3(ceil_div(B, 16)), dim3(64), bp_bytes, (hipStream_t)stream, B, L, feats, lengths, trans, best_score,
                        paths);
   else
     hipLaunchKernelGGL(crf_viterbi_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, B, L, C, feats, lengths, trans, best_score, paths, bp_ws);

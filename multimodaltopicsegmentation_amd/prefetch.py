@@ -25,6 +25,8 @@ import threading
 
 import torch
 
+from .encoder_dataset import release_after
+
 _FLOAT_FIELDS = ('src_tokens', 'src_tokens2', 'tgt_tokens')
 _WIRE_FIELDS = ('src_tokens', 'src_tokens2')
 
@@ -81,6 +83,7 @@ class DevicePrefetcher:
                 ev = torch.cuda.Event()
                 ev.record(self._stream)
             self._slot_done[slot] = ev
+            release_after(batch, ev)                                  # a collater that pads into its own pinned ring (encoder_dataset.py) reuses the slot after this
         else:
             for f in _FLOAT_FIELDS:
                 t = batch.get(f)

@@ -210,6 +210,7 @@ class _TaggerBase(FlatModule):
     # (a span of adjacent tensors; q/k/v are three tensors in the HF layout and one packed in_proj in the legacy one).
     # Needs self.embedding_dim, self.nheads, self._ffp (FFN width as stored), self.ln_eps, self.ffn_act ('gelu' | 'relu').
     ffn_act = 'gelu'
+    qkv_release = os.environ.get('MTS_DP_QKV_RELEASE', 'block')    # under a data-parallel hook: 'projection' | 'block' (see _band_layer_bwd)
     fuse_ffn = os.environ.get('MTS_FUSE_FFN', '1') != '0'    # one launch per direction for the feed-forward block where mts_ffn_* covers it
                                                               # (bf16, F = 256, d a multiple of 256, no hidden dropout); bitwise the same results
     fuse_ffn_min_rows = 12288        # ... and where its 64-row workgroups fill the chip: below ~192 workgroups the 128x128 GEMM pair is
@@ -349,9 +350,11 @@ class _TaggerBase(FlatModule):
         ops.band_attn_bwd(S['qkv'], lengths_i32, S['probs'], dctx, B, Lq, D, H, S['radius'], dqkv, dsc,
                           dbias=Gv('bqkv', 1, 3 * D).view(-1), row0=row0, drop_p=S['pattn'], drop_seed=S['aseed'])
         o_qkv = lay.entries[names['wqkv'][0]][0]
-        if self._grad_hook is not None:
+        if self._grad_hook is not None and self.qkv_release == 'projection':
             # data parallel: one weight-gradient GEMM per projection, each third handed to the exchange as soon as it is final --
-            # what is still in flight when the backward ends is the last 12.8 MB instead of the whole 38.5 MB q/k/v block
+            # what is still in flight when the backward ends is the last 12.8 MB instead of the whole 38.5 MB q/k/v block.  Costs three
+            # launches of 1792 x 1792 x rows (98 us each at 16384 rows) against one of 5376 x 1792 x rows (276 us): qkv_release = 'block'
+            # (MTS_DP_QKV_RELEASE=block) keeps the one GEMM and announces the whole block behind it
             gq = Gv('wqkv', 3 * D, D)
             for i in range(3):
                 wgrad(dqkv[:, i * D:(i + 1) * D], S['hin'], gq[i * D:(i + 1) * D])

@@ -499,6 +499,51 @@ def test_crf_nll_viterbi(ops):
     assert [paths[b, :n].cpu().tolist() for b, n in enumerate(lengths.tolist())] == rp
 
 
+@pytest.mark.parametrize('B,Lq,scale', [(20, 2437, 1.0), (3, 4000, 4.0), (1, 2437, 1.0)])
+def test_crf_long_documents(ops, B, Lq, scale):
+    """CRF NLL in the scaled probability domain and the 2-bit back-pointer Viterbi at predict.py's document lengths (RadioNews: up to 2 437
+    sentences; one document per call) and beyond the first version's 64-KB limit: loss, emission / transition gradients and every Viterbi
+    tag against the fp64 oracle.  scale 4: emission rows whose maximum sits on the START tag (nobody can move there) and spreads of +-15."""
+    g = torch.Generator().manual_seed(77)
+    C = 4
+    lengths = torch.randint(Lq // 2, Lq + 1, (B,), generator=g)
+    lengths[0] = Lq
+    if B > 2:
+        lengths[1] = 1
+    feats = torch.randn(B, Lq, C, generator=g) * scale
+    if scale > 1:
+        feats[:, ::3, C - 2] += 12.0                   # START carries the row maximum on every third step
+    trans = torch.randn(C, C, generator=g)
+    trans[C - 2, :] = R.IMPOSSIBLE
+    trans[:, C - 1] = R.IMPOSSIBLE
+    tags = torch.zeros(B, Lq)
+    for b, n in enumerate(lengths.tolist()):
+        tags[b, :n] = (torch.rand(n, generator=g) < 0.3).float()
+    f64 = feats.double().requires_grad_(True)
+    t64 = trans.double().requires_grad_(True)
+    mask = R.create_mask(Lq, lengths).double()
+    ref = (R.crf_forward_score(f64, mask, t64) - R.crf_gold_score(f64, tags.long(), mask, t64)).mean()
+    ref.backward()
+    out = torch.empty(2, device=DEV)
+    df = torch.full((B, Lq, C), float('nan'), device=DEV)
+    dt = torch.empty(C, C, device=DEV)
+    li32 = lengths.to(torch.int32).to(DEV)
+    ops.crf_nll(feats.to(DEV), tags.to(DEV), li32, trans.to(DEV), out, df, dt)
+    assert abs(float(out[0]) - ref.item()) < 2e-6 * abs(ref.item()), (float(out[0]), ref.item())
+    assert not torch.isnan(df).any()
+    _close(df, f64.grad, 1e-3, 2e-5 / B, 'dfeats')              # (the reference's gradient carries the 1 / B of the batch mean)
+    _close(dt, t64.grad, 1e-3, 1e-4, 'dtrans')
+    score = torch.empty(B, device=DEV)
+    paths = torch.empty(B, Lq, dtype=torch.int32, device=DEV)
+    ops.crf_viterbi(feats.to(DEV), li32, trans.to(DEV), score, paths)
+    eye = torch.eye(C, dtype=torch.float64)
+    rs, rp = R.crf_viterbi(feats.double(), mask, eye, torch.zeros(C, dtype=torch.float64), trans.double())
+    _close(score, rs, 1e-5, 1e-3, 'viterbi score')
+    got = [paths[b, :n].cpu().tolist() for b, n in enumerate(lengths.tolist())]
+    assert got == rp
+    assert bool((paths.cpu()[0, lengths[0]:] == -1).all()) and (B < 3 or bool((paths.cpu()[1, 1:] == -1).all()))
+
+
 # ------------------------------------------------------------------------------------------------ optimizers
 def test_adam_and_sgd_match_torch(ops):
     n = 10007

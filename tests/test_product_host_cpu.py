@@ -30,6 +30,79 @@ def test_product_collater_matches_reference_fixture():
     assert ds.collater([]) == {}
 
 
+def test_pinned_ring_collater_produces_the_reference_batch_in_fp32_and_its_bf16_rounding():
+    """AudioPortionDataset(pin_memory=True, wire_dtype=...): the native one-pass collater (mts_collate_pad) into a ring of reusable host
+    buffers against the SAME g8 records -- fp32: bit for bit the reference's batch; bf16: bit for bit `reference_batch.to(torch.bfloat16)`
+    (round to nearest even); lengths, ids, targets untouched.  Ring slots are handed out round-robin, a slot registered as busy
+    (release_after) is waited for before it is written again, and a batch stays intact until its slot comes round."""
+    from multimodaltopicsegmentation_amd import AudioPortionDataset
+    from multimodaltopicsegmentation_amd.encoder_dataset import release_after
+    g = H.load('g8_collater')
+    lens = g['lens'].tolist()
+    lines = [(torch.from_numpy(g[f'emb{i}']), g[f'tgt{i}'].tolist(), f'doc{n}') for i, n in enumerate(lens)]
+    lines2 = [(torch.from_numpy(g[f'emb2_{i}']), None, f'doc{n}') for i, n in enumerate(lens)]
+    for wire, dt in (('fp32', torch.float32), ('bf16', torch.bfloat16)):
+        for crf in (True, False):
+            for trunc, tv in ((False, 100), (True, 5), (True, 16)):
+                ds = AudioPortionDataset(lines, {'0': 0, '1': 1}, CRF=crf, truncate=trunc, truncate_value=tv, second_input=lines2,
+                                         pin_memory=True, wire_dtype=wire, pin_slots=2, collate_threads=3)
+                b = ds.collater([ds[i] for i in range(len(ds))])
+                key = f'crf{int(crf)}_tr{int(trunc)}_{tv}.'
+                assert sorted(b.keys()) == ['domain', 'id', 'src_lengths', 'src_tokens', 'src_tokens2', 'tgt_tokens']
+                for f in ('src_tokens', 'src_tokens2'):
+                    want = torch.from_numpy(g[key + f]).to(dt)
+                    assert b[f].dtype == dt and b[f].shape == want.shape, (key, f)
+                    assert torch.equal(b[f].view(torch.int16 if dt == torch.bfloat16 else torch.int32),
+                                       want.view(torch.int16 if dt == torch.bfloat16 else torch.int32)), (wire, key, f)
+                for f in ('tgt_tokens', 'src_lengths', 'id'):
+                    np.testing.assert_array_equal(b[f].numpy(), g[key + f], err_msg=key + f)
+    # the ring: two slots -> the third batch reuses the first one's memory, and only after its registered copy event has been waited for
+    ds = AudioPortionDataset(lines, {'0': 0, '1': 1}, CRF=False, truncate=False, pin_memory=True, pin_slots=2)
+    samples = [ds[i] for i in range(len(ds))]
+
+    class Ev:
+        waited = 0
+
+        def synchronize(self):
+            Ev.waited += 1
+    b1 = ds.collater(samples)
+    keep = b1['src_tokens'].clone()
+    release_after(b1, Ev())
+    b2 = ds.collater(samples[::-1])
+    assert b2['src_tokens'].data_ptr() != b1['src_tokens'].data_ptr() and torch.equal(b1['src_tokens'], keep) and Ev.waited == 0
+    b3 = ds.collater(samples)
+    assert b3['src_tokens'].data_ptr() == b1['src_tokens'].data_ptr() and Ev.waited == 1
+    # the batched fetch of a DataLoader (__getitems__ -> indices -> pointer tables): the same batch as the per-sample path, every field
+    from torch.utils.data import DataLoader
+    for crf in (True, False):
+        dsf = AudioPortionDataset(lines, {'0': 0, '1': 1}, CRF=crf, truncate=True, truncate_value=16, second_input=lines2, pin_memory=True)
+        slow = dsf.collater([dsf[i] for i in (2, 0, 1)])
+        slow = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in slow.items()}
+        fast = dsf.collater(dsf.__getitems__([2, 0, 1]))
+        assert sorted(fast.keys()) == sorted(slow.keys())
+        for k in slow:
+            if isinstance(slow[k], torch.Tensor):
+                assert fast[k].dtype == slow[k].dtype and torch.equal(fast[k], slow[k]), k
+            else:
+                assert fast[k] == slow[k], k
+        batches = list(DataLoader(dsf, batch_size=2, shuffle=False, collate_fn=dsf.collater))
+        assert len(batches) == (len(lens) + 1) // 2 and batches[0]['id'].tolist() == [0, 1]
+        ref_ds = AudioPortionDataset(lines, {'0': 0, '1': 1}, CRF=crf, truncate=True, truncate_value=16, second_input=lines2)
+        want = ref_ds.collater([ref_ds[0], ref_ds[1]])
+        for k in ('src_tokens', 'src_tokens2', 'tgt_tokens', 'src_lengths', 'id'):
+            assert torch.equal(batches[0][k], want[k]), k
+    # a big batch takes the threaded path: 24 documents x up to 300 rows x 512 columns in six threads, ragged, against the plain collater
+    gen = torch.Generator().manual_seed(3)
+    big = [(torch.randn(int(n), 512, generator=gen), [0] * int(n), 'x') for n in torch.randint(1, 301, (24,), generator=gen)]
+    ref = AudioPortionDataset(big, None, CRF=False, truncate=True, truncate_value=256)
+    want = ref.collater([ref[i] for i in range(24)])
+    for wire, dt in (('fp32', torch.float32), ('bf16', torch.bfloat16)):
+        fast = AudioPortionDataset(big, None, CRF=False, truncate=True, truncate_value=256, pin_memory=True, wire_dtype=wire, collate_threads=6)
+        got = fast.collater([fast[i] for i in range(24)])
+        assert torch.equal(got['src_tokens'], want['src_tokens'].to(dt)) and torch.equal(got['src_lengths'], want['src_lengths'])
+        assert torch.equal(got['tgt_tokens'], want['tgt_tokens'])
+
+
 def test_product_inference_collater_matches_reference_fixture():
     """AudioPortionDatasetInference.collater (EncoderDataset.py:198-232), incl. the truncate quirk: lengths = truncate_value."""
     from multimodaltopicsegmentation_amd import AudioPortionDatasetInference

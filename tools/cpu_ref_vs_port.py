@@ -2,7 +2,7 @@
 """Build container only (needs /root/reference): time the REFERENCE's own CPU path against this repo's CPU port
 (oracle/restatement.py, the thing bench.py's cpu_baseline runs on the GPU box) on the same sample, same threads:
 
-    python tools/cpu_ref_vs_port.py [--docs 8] [--threads 8]  ->  profiles/r02_cpu_ref_vs_port.json
+    python tools/cpu_ref_vs_port.py [--docs 8] [--threads 8]  ->  profiles/r04_cpu_ref_vs_port.json
 
 BASELINE configs[1] model (d=1792, 8 heads, ff 256, window 30 = radius 15, 1 layer, focal loss), fp32, one optimizer step =
 forward + backward + Adam(eps 1e-7); best of 3 after one warm-up.  bench.py quotes the resulting ratio in cpu_baseline.sample so
@@ -97,7 +97,7 @@ def main():
         out[name + '_vs_reference'] = t_ref / t          # > 1: the port is FASTER than the reference
     out['cpu'] = next((l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name')), '?')
     print(json.dumps(out, indent=1))
-    with open(os.path.join(ROOT, 'profiles', 'r02_cpu_ref_vs_port.json'), 'w') as f:
+    with open(os.path.join(ROOT, 'profiles', 'r04_cpu_ref_vs_port.json'), 'w') as f:
         json.dump(out, f, indent=1)
 
 
