@@ -509,16 +509,16 @@ def main():
         # roofline of the dominant kernel (by total time).  One GEMM symbol = one (layout, output dtype, tile) instantiation;
         # the timed region of a weight-gradient call also holds its split-K reduce kernel (named in the label).
         sym = {(0, 128): 'gemm_bf16_kernel<NT,bf16,GLDS> (128x128)', (1, 128): 'gemm_bf16_kernel<NN,bf16,GLDS> (128x128)',
-               (2, 128): 'gemm_bf16_kernel<TN,f32,GLDS> (128x128) + splitk_reduce_kernel',
-               (0, 224): 'gemm_bf16_224d_kernel<NT,bf16> (256x224, four waves, LDS-DMA)', (1, 224): 'gemm_bf16_224_kernel<NN,bf16> (256x224)',
-               (2, 224): 'gemm_bf16_224_kernel<TN,f32> (256x224) + splitk_reduce_kernel',
+               (2, 128): 'gemm_bf16_kernel<TN,f32,GLDS> (128x128)',
+               (0, 224): 'gemm_bf16_224p_kernel<NT,bf16> (256x224, four waves, LDS-DMA, persistent)', (1, 224): 'gemm_bf16_224_kernel<NN,bf16> (256x224)',
+               (2, 224): 'gemm_bf16_224t_kernel<TN,f32> (256x224, four waves, LDS-DMA, 32-deep units)',
                (0, 256): 'gemm_bf16_256_kernel<NT,bf16> (256x256)', (1, 256): 'gemm_bf16_256_kernel<NN,bf16> (256x256)',
-               (2, 256): 'gemm_bf16_256_kernel<TN,f32> (256x256) + splitk_reduce_kernel'}
+               (2, 256): 'gemm_bf16_256_kernel<TN,f32> (256x256)'}
         rocprof_names = {(0, 128): ['void gemm_bf16_kernel<0, bool _Accum, bool, E>(GemmArgs)'], (1, 128): ['void gemm_bf16_kernel<1, bool _Accum, bool, E>(GemmArgs)'],
-                         (2, 128): ['void gemm_bf16_kernel<2, float, true>(GemmArgs)', 'splitk_reduce_kernel(float const*, int, int, int, float*, int, int)'],
-                         (0, 224): ['gemm_bf16_224d_kernel(GemmArgs)', '_Z20gemm_bf16_224_kernelILi0EDF16bLb0ELb1EEv8GemmArgs'], (1, 224): ['_Z20gemm_bf16_224_kernelILi1EDF16bLb0ELb1EEv8GemmArgs'],
-                         (2, 224): ['void gemm_bf16_224_kernel<2, float, true, true>(GemmArgs)', 'splitk_reduce_kernel(float const*, int, int, int, float*, int, int)'],
-                         (2, 256): ['void gemm_bf16_256_kernel<2, float, true>(GemmArgs)', 'splitk_reduce_kernel(float const*, int, int, int, float*, int, int)'],
+                         (2, 128): ['void gemm_bf16_kernel<2, float, true>(GemmArgs)'],
+                         (0, 224): ['gemm_bf16_224p_kernel(GemmArgs)', 'gemm_bf16_224d_kernel(GemmArgs)'], (1, 224): ['_Z20gemm_bf16_224_kernelILi1EDF16bLb0ELb1EEv8GemmArgs'],
+                         (2, 224): ['gemm_bf16_224t_kernel(GemmArgs, int)'],
+                         (2, 256): ['void gemm_bf16_256_kernel<2, float, true>(GemmArgs)'],
                          (0, 256): ['_Z20gemm_bf16_256_kernelILi0EDF16bLb0EEv8GemmArgs'], (1, 256): ['_Z20gemm_bf16_256_kernelILi1EDF16bLb0EEv8GemmArgs']}
         def aggregate(summary):
             per_sym, other = {}, {}
@@ -555,7 +555,7 @@ def main():
                                'algorithmic_gflop_per_launch': dom['flop'] / dom['launches'] / 1e9}
             if traffic_note:
                 out['roofline']['traffic_note'] = traffic_note
-            out['kernels_note'] = 'per-launch averages from the warm-up steps (every GEMM / band launch bracketed by HIP events); the roofline entry and band_attn_fwd are from the timed region'
+            out['kernels_note'] = 'per-launch averages from the warm-up steps (every GEMM / band launch bracketed by HIP events; the bracket of a split-K weight gradient ends before its reduce launch: mts_gemm_set_mid_hook); the roofline entry and band_attn_fwd are from the timed region'
             out['kernels'] = {sym.get(k, str(k)): {'launches': d['launches'], 'avg_us': 1e3 * d['ms'] / d['launches'],
                                                     'tflops': d['flop'] / (d['ms'] * 1e-3) / 1e12} for k, d in wper_sym.items()}
             # the HBM-bound headline kernel: band attention, 14 336 algorithmic bytes per sentence (bf16 q,k,v in, ctx out)

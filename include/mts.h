@@ -84,6 +84,9 @@ int mts_set_option(const char* key, int value);
 int mts_async_status(void);
 /* tile width (128 | 224 | 256) and K split the cost model chose for the calling thread's most recent bf16 mts_gemm (bench / profiling labels) */
 int mts_gemm_last_plan(int* tile, int* splits);
+/* Measurement aid (per host thread; NULL clears it): fn() is called between the GEMM launch and the split-K reduce launch of every bf16 mts_gemm,
+ * so that an event bracket can time the GEMM kernel by itself. */
+int mts_gemm_set_mid_hook(void (*fn)(void));
 /* The planner by itself (pure host code, no device call): the tile width and K split mts_gemm WOULD use for this call under the
  * calling thread's options; workspace_bytes = 0 means "no split-K workspace".  tile / splits may be NULL. */
 int mts_gemm_plan(int a_dtype, int c_dtype, int layout, int M, int N, int K, unsigned epilogue, size_t workspace_bytes,

@@ -46,6 +46,7 @@ SIGNATURES = {
     'mts_version': (C.c_char_p, []),
     'mts_set_option': (_i, [C.c_char_p, _i]),
     'mts_gemm_last_plan': (_i, [_vp, _vp]),
+    'mts_gemm_set_mid_hook': (_i, [_vp]),
     'mts_gemm_plan': (_i, [_i, _i, _i, _i, _i, _i, _u, _sz, _vp, _vp]),
     'mts_async_status': (_i, []),
     'mts_gemm': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _u, _f, _i, _vp, _sz]),

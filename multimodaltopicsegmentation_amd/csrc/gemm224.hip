@@ -705,15 +705,18 @@ static int launch_one(const GemmArgs& a, int splits, hipStream_t st) {
 
 int mts_launch_gemm224r(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st);   // gemm224r.hip: four-wave register-staged form
 int mts_launch_gemm224t(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st);   // gemm224t.hip: four-wave weight-gradient (TN) form
+int mts_launch_gemm224p(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st);   // gemm224p.hip: four-wave persistent forward (NT) form
 
 // called from mts_gemm (gemm.hip) when N is a multiple of 224 and the 224-wide tiling fills the CUs better
 int mts_launch_gemm224(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st) {
   // bf16 C, NT (the forward projections): the four-wave kernel with buffer-load LDS-DMA (gemm224r.hip, gemm_bf16_224d_kernel) where it applies --
   // bitwise the same results, 4 % faster back to back on the step's shapes, 8-10 % at deep K.  gemm_variant 6 keeps the eight-wave kernel (A/B).
   if (a.variant == 0 && !c_is_f32 && layout == MTS_NT && splits == 1) {
+    int rc = mts_launch_gemm224p(a, layout, c_is_f32, splits, st);          // persistent form (gemm224p.hip); gemm_variant 9: one tile per workgroup
+    if (rc >= 0) return rc;
     GemmArgs b = a;
     b.variant = 9;
-    const int rc = mts_launch_gemm224r(b, layout, c_is_f32, splits, st);
+    rc = mts_launch_gemm224r(b, layout, c_is_f32, splits, st);
     if (rc >= 0) return rc;
   }
   // fp32 C, TN (the weight gradients): the four-wave unit-pipelined kernel (gemm224t.hip) where it applies; gemm_variant 6 keeps the eight-wave kernel

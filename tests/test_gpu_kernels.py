@@ -538,7 +538,7 @@ def test_crf_long_documents(ops, B, Lq, scale):
     ops.crf_viterbi(feats.to(DEV), li32, trans.to(DEV), score, paths)
     eye = torch.eye(C, dtype=torch.float64)
     rs, rp = R.crf_viterbi(feats.double(), mask, eye, torch.zeros(C, dtype=torch.float64), trans.double())
-    _close(score, rs, 1e-5, 1e-3, 'viterbi score')
+    _close(score, rs, 5e-5, 1e-3, 'viterbi score')                 # (an fp32 running sum over thousands of steps)
     got = [paths[b, :n].cpu().tolist() for b, n in enumerate(lengths.tolist())]
     assert got == rp
     assert bool((paths.cpu()[0, lengths[0]:] == -1).all()) and (B < 3 or bool((paths.cpu()[1, 1:] == -1).all()))
