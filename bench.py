@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-PMC_TRAFFIC_FILE = 'r03_pmc_traffic.json'   # written by tools/pmc_traffic.py from two rocprofv3 --pmc passes, stamped with csrc_sha()
+PMC_TRAFFIC_FILE = 'r04_pmc_traffic.json'   # written by tools/pmc_traffic.py from two rocprofv3 --pmc passes, stamped with csrc_sha()
 
 
 def fwd_bwd_mflop_per_sentence(D, ff, radius, n_layers, n_out=1):

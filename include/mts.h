@@ -292,6 +292,12 @@ int mts_lstm_fwd(void* stream, int dtype, int B, int L, int H, int ndir, const v
 int mts_lstm_bwd(void* stream, int dtype, int B, int L, int H, int ndir, const float* w_hh, const int32_t* lengths,
                  const void* out, const void* gates, const float* cells, const void* dout, void* dxproj,
                  float* dw_hh, void* workspace);
+/* mts_lstm_bwd in two calls (recurrence | h_{t-1} + dW_hh), so that the weight-gradient half can run on another stream while the caller's next
+ * dependent launch follows the recurrence directly.  `workspace`: the same buffer for both calls of a layer, untouched in between. */
+int mts_lstm_bwd_recurrence(void* stream, int dtype, int B, int L, int H, int ndir, const float* w_hh, const int32_t* lengths,
+                            const void* out, const void* gates, const float* cells, const void* dout, void* dxproj, void* workspace);
+int mts_lstm_bwd_whh(void* stream, int dtype, int B, int L, int H, int ndir, const int32_t* lengths, const void* out, const void* dxproj,
+                     float* dw_hh, void* workspace);
 
 /* ---------------------------------------------------------------------------------------------
  * CRF head.  Replaces models/CRF.py:98-240 (fc output = `feats` is produced by mts_gemm/mts_head_fwd).

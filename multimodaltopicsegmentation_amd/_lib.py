@@ -82,6 +82,8 @@ SIGNATURES = {
     'mts_lstm_workspace': (_sz, [_i, _i, _i, _i, _i]),
     'mts_lstm_fwd': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'mts_lstm_bwd': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'mts_lstm_bwd_recurrence': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'mts_lstm_bwd_whh': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'mts_crf_workspace': (_sz, [_i, _i, _i]),
     'mts_crf_nll': (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'mts_crf_viterbi': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

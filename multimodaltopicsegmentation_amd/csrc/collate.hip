@@ -13,7 +13,24 @@
 #include <mutex>
 #include <condition_variable>
 #include <functional>
+#include <emmintrin.h>
 #include "common.h"
+
+// Same-dtype rows go out with non-temporal 16-byte stores: the destination (a pinned ring slot the GPU's DMA engine reads next) is written
+// once and not read by the host, and an ordinary store first READS the line it is about to overwrite -- a third more memory traffic for a
+// pass that is memory-bound.  (glibc's memcpy switches to such stores only above several MB per call; a document's piece is < 1 MB.)
+static inline void copy_stream(char* d, const char* s, size_t n) {
+  if ((((uintptr_t)d | n) & 15) != 0) { memcpy(d, s, n); return; }
+  const __m128i* sp = (const __m128i*)s;
+  __m128i* dp = (__m128i*)d;
+  const size_t v = n >> 4;
+  size_t k = 0;
+  for (; k + 4 <= v; k += 4) {
+    const __m128i a = _mm_loadu_si128(sp + k), b = _mm_loadu_si128(sp + k + 1), c = _mm_loadu_si128(sp + k + 2), e = _mm_loadu_si128(sp + k + 3);
+    _mm_stream_si128(dp + k, a); _mm_stream_si128(dp + k + 1, b); _mm_stream_si128(dp + k + 2, c); _mm_stream_si128(dp + k + 3, e);
+  }
+  for (; k < v; ++k) _mm_stream_si128(dp + k, _mm_loadu_si128(sp + k));
+}
 
 // A small persistent pool: starting a thread costs 20-30 us, sixteen of them per call were a fifth of a 58-MB collation.  One job at a time
 // (calls are serialised by a mutex: the collater runs on one producer thread); workers sleep on a condition variable between jobs.
@@ -86,7 +103,7 @@ static void collate_rows(int src_dtype, int dst_dtype, int Lmax, int D, const vo
       const char* s = (const char*)docs[b] + (size_t)i * D * ssz;
       const size_t n = (size_t)ncopy * D;
       if (src_dtype == dst_dtype) {
-        memcpy(d, s, n * dsz);
+        copy_stream(d, s, n * dsz);
       } else if (src_dtype == MTS_F32) {                                               // fp32 -> bf16
         const uint32_t* sp = (const uint32_t*)s;
         uint16_t* dp = (uint16_t*)d;
@@ -106,6 +123,7 @@ static void collate_rows(int src_dtype, int dst_dtype, int Lmax, int D, const vo
     }
     r = end;
   }
+  _mm_sfence();                                            // the streamed rows are globally visible before the caller enqueues the DMA
 }
 
 extern "C" int mts_collate_pad(int src_dtype, int dst_dtype, int B, int Lmax, int D, const void* const* docs, const int64_t* doc_rows, void* dst,

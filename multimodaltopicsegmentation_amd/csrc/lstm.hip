@@ -223,6 +223,7 @@ int mts_lstm_pair_bwd(hipStream_t st, int B, int L, int H, int ndir, const float
 // CU-quad recurrences in fp32 (lstm_pair.hip), H = 256: parity mode
 int mts_lstm_quad_f32_fwd(hipStream_t st, int B, int L, int H, int ndir, const void* xproj, const float* w_hh, const float* b_hh,
                           const int32_t* lengths, void* out, void* gates, float* cells, void* ws);
+int mts_lstm_pair_hprev(hipStream_t st, int dtype, int B, int L, int H, int ndir, const int32_t* lengths, const void* out, void* hprev);
 int mts_lstm_quad_f32_bwd(hipStream_t st, int B, int L, int H, int ndir, const float* w_hh, const int32_t* lengths, const void* out, const void* gates,
                           const float* cells, const void* dout, void* dxproj, void* hprev, void* ws);
 unsigned mts_lstm_pair_take_error();                  // lstm_pair.hip: sticky timeout word (pinned host memory), reading clears
@@ -285,45 +286,56 @@ extern "C" int mts_lstm_fwd(void* stream, int dtype, int B, int L, int H, int nd
   return MTS_OK;
 }
 
-extern "C" int mts_lstm_bwd(void* stream, int dtype, int B, int L, int H, int ndir, const float* w_hh, const int32_t* lengths, const void* out,
-                            const void* gates, const float* cells, const void* dout, void* dxproj, float* dw_hh, void* workspace) {
-  MTS_CHECK_ARG(B > 0 && L > 0 && H > 0 && (ndir == 1 || ndir == 2), "mts_lstm_bwd: bad shape");
-  MTS_CHECK_ARG(w_hh && out && gates && cells && dout && dxproj && dw_hh && workspace, "mts_lstm_bwd: null pointer");
-  MTS_CHECK_ARG(dtype == MTS_F32 || dtype == MTS_BF16, "mts_lstm_bwd: bad dtype %d", dtype);
-  MTS_UNSUPPORTED(H <= 1024, "mts_lstm_bwd: hidden size %d > 1024", H);
-  if (int rc = lstm_report_async("mts_lstm_bwd")) return rc;
+// part 1: the recurrence (dxproj; + h_{t-1} where the kernel produces it itself), 2: dW_hh (+ h_{t-1} for the CU-pair / CU-quad paths), 3: both
+static int lstm_bwd_impl(int part, void* stream, int dtype, int B, int L, int H, int ndir, const float* w_hh, const int32_t* lengths, const void* out,
+                         const void* gates, const float* cells, const void* dout, void* dxproj, float* dw_hh, void* workspace) {
+  const char* who = part == 1 ? "mts_lstm_bwd_recurrence" : part == 2 ? "mts_lstm_bwd_whh" : "mts_lstm_bwd";
+  MTS_CHECK_ARG(B > 0 && L > 0 && H > 0 && (ndir == 1 || ndir == 2), "%s: bad shape", who);
+  MTS_CHECK_ARG(out && dxproj && workspace, "%s: null pointer", who);
+  MTS_CHECK_ARG(!(part & 1) || (w_hh && gates && cells && dout), "%s: null pointer", who);
+  MTS_CHECK_ARG(!(part & 2) || dw_hh, "%s: null pointer", who);
+  MTS_CHECK_ARG(dtype == MTS_F32 || dtype == MTS_BF16, "%s: bad dtype %d", who, dtype);
+  MTS_UNSUPPORTED(H <= 1024, "%s: hidden size %d > 1024", who, H);
+  if (int rc = lstm_report_async(who)) return rc;
   hipStream_t st = (hipStream_t)stream;
   const size_t hoff = lstm_scratch_bytes(B, H, ndir);
   char* hprev = (char*)workspace + hoff;
-  const bool fast = g_lstm_mfma && (mts_lstm_mfma_supported(dtype, H) || mts_lstm_pair_supported(dtype, H));
-  if (fast) {
-    int rc = mts_lstm_pair_supported(dtype, H)
-                 ? (dtype == MTS_F32 ? mts_lstm_quad_f32_bwd(st, B, L, H, ndir, w_hh, lengths, out, gates, cells, dout, dxproj, hprev, workspace)
-                                     : mts_lstm_pair_bwd(st, B, L, H, ndir, w_hh, lengths, out, gates, cells, dout, dxproj, hprev, workspace))
-                 : mts_lstm_mfma_bwd(st, B, L, H, ndir, w_hh, lengths, out, gates, cells, dout, dxproj, hprev, workspace);
-    if (rc) return rc;
+  const bool pairq = g_lstm_mfma && mts_lstm_pair_supported(dtype, H);
+  const bool fast = g_lstm_mfma && (mts_lstm_mfma_supported(dtype, H) || pairq);
+  if (part & 1) {
+    if (fast) {
+      // the CU-pair / CU-quad recurrences take h_{t-1} from a kernel of its own: with the recurrence when both parts run here, otherwise with part 2
+      void* hp = (part & 2) ? (void*)hprev : nullptr;
+      int rc = pairq ? (dtype == MTS_F32 ? mts_lstm_quad_f32_bwd(st, B, L, H, ndir, w_hh, lengths, out, gates, cells, dout, dxproj, hp, workspace)
+                                         : mts_lstm_pair_bwd(st, B, L, H, ndir, w_hh, lengths, out, gates, cells, dout, dxproj, hp, workspace))
+                     : mts_lstm_mfma_bwd(st, B, L, H, ndir, w_hh, lengths, out, gates, cells, dout, dxproj, hprev, workspace);
+      if (rc) return rc;
+    } else {
+      const size_t lds = (size_t)LSTM_DG * 4 * H * sizeof(float);
+      MTS_UNSUPPORTED(lds <= 160 * 1024, "%s: hidden size %d needs too much LDS", who, H);
+      dim3 grid(ceil_div(B, LSTM_DG), ndir), block(lstm_threads(H));
+      if (dtype == MTS_F32) {
+        auto k = lstm_bwd_kernel<float>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, grid, block, lds, st, B, L, H, ndir, w_hh, lengths, (const float*)out, (const float*)gates, cells, (const float*)dout,
+                           (float*)dxproj, (float*)hprev);
+      } else {
+        auto k = lstm_bwd_kernel<bf16_t>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, grid, block, lds, st, B, L, H, ndir, w_hh, lengths, (const bf16_t*)out, (const bf16_t*)gates, cells, (const bf16_t*)dout,
+                           (bf16_t*)dxproj, (bf16_t*)hprev);
+      }
+    }
+    MTS_LAUNCH_CHECK(who);
   }
-  const size_t lds = (size_t)LSTM_DG * 4 * H * sizeof(float);
-  MTS_UNSUPPORTED(lds <= 160 * 1024, "mts_lstm_bwd: hidden size %d needs too much LDS", H);
-  dim3 grid(ceil_div(B, LSTM_DG), ndir), block(lstm_threads(H));
-  if (fast) {
-    // recurrence done above
-  } else if (dtype == MTS_F32) {
-    auto k = lstm_bwd_kernel<float>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, grid, block, lds, st, B, L, H, ndir, w_hh, lengths, (const float*)out, (const float*)gates, cells, (const float*)dout,
-                       (float*)dxproj, (float*)hprev);
-  } else {
-    auto k = lstm_bwd_kernel<bf16_t>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, grid, block, lds, st, B, L, H, ndir, w_hh, lengths, (const bf16_t*)out, (const bf16_t*)gates, cells, (const bf16_t*)dout,
-                       (bf16_t*)dxproj, (bf16_t*)hprev);
+  if (!(part & 2)) return MTS_OK;
+  if (part == 2 && pairq) {
+    if (int rc = mts_lstm_pair_hprev(st, dtype, B, L, H, ndir, lengths, out, hprev)) return rc;
   }
-  MTS_LAUNCH_CHECK("mts_lstm_bwd");
   // dW_hh[d] = dA_d^T [4H, B*L] . Hprev_d [B*L, H]
   const size_t esz = dtype == MTS_F32 ? 4 : 2;
   const bool mfma_ok = (dtype == MTS_F32) || ((4 * H) % 8 == 0 && H % 8 == 0 && (ndir * 4 * H) % 8 == 0 && (ndir * H) % 8 == 0);
-  MTS_UNSUPPORTED(mfma_ok, "mts_lstm_bwd(bf16): hidden size %d must be a multiple of 8", H);
+  MTS_UNSUPPORTED(mfma_ok, "%s(bf16): hidden size %d must be a multiple of 8", who, H);
   for (int d = 0; d < ndir; ++d) {
     int rc = mts_gemm(stream, dtype, MTS_F32, MTS_TN, 4 * H, H, B * L, (const char*)dxproj + (size_t)d * 4 * H * esz, ndir * 4 * H,
                       hprev + (size_t)d * H * esz, ndir * H, dw_hh + (size_t)d * 4 * H * H, H, nullptr, nullptr, 0, nullptr, 0, 0u, 1.f, 0,
@@ -331,4 +343,21 @@ extern "C" int mts_lstm_bwd(void* stream, int dtype, int B, int L, int H, int nd
     if (rc) return rc;
   }
   return MTS_OK;
+}
+
+extern "C" int mts_lstm_bwd(void* stream, int dtype, int B, int L, int H, int ndir, const float* w_hh, const int32_t* lengths, const void* out,
+                            const void* gates, const float* cells, const void* dout, void* dxproj, float* dw_hh, void* workspace) {
+  return lstm_bwd_impl(3, stream, dtype, B, L, H, ndir, w_hh, lengths, out, gates, cells, dout, dxproj, dw_hh, workspace);
+}
+// The two halves of mts_lstm_bwd as calls of their own, so that a caller can put the weight-gradient half on another stream: the recurrent
+// taggers' next dependent launch (the data gradient of the layer below) then starts right behind the recurrence instead of behind
+// h_{t-1} + two split-K GEMMs + their reduces (~80 us per layer at 64 x 256, H = 256).  `workspace`: the SAME buffer for both calls of a layer, not
+// touched by anything else in between (mts_lstm_bwd_whh finds h_{t-1} there or builds it there, and uses the recurrence's scratch for its slabs).
+extern "C" int mts_lstm_bwd_recurrence(void* stream, int dtype, int B, int L, int H, int ndir, const float* w_hh, const int32_t* lengths, const void* out,
+                                       const void* gates, const float* cells, const void* dout, void* dxproj, void* workspace) {
+  return lstm_bwd_impl(1, stream, dtype, B, L, H, ndir, w_hh, lengths, out, gates, cells, dout, dxproj, nullptr, workspace);
+}
+extern "C" int mts_lstm_bwd_whh(void* stream, int dtype, int B, int L, int H, int ndir, const int32_t* lengths, const void* out, const void* dxproj,
+                                float* dw_hh, void* workspace) {
+  return lstm_bwd_impl(2, stream, dtype, B, L, H, ndir, nullptr, lengths, out, nullptr, nullptr, nullptr, const_cast<void*>(dxproj), dw_hh, workspace);
 }

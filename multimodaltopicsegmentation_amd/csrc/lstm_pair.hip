@@ -1083,6 +1083,19 @@ __global__ void lstm_hprev_kernel(int B, int L, int H, int ndir, const int32_t* 
   store4<T>(hprev + row * ndir * H + c, v);
 }
 
+// h_{t-1} of every (document, step) as a matrix [B*L, ndir*H] -- the second operand of the dW_hh GEMMs (the CU-pair / CU-quad recurrences do
+// not produce it themselves)
+int mts_lstm_pair_hprev(hipStream_t st, int dtype, int B, int L, int H, int ndir, const int32_t* lengths, const void* out, void* hprev) {
+  const size_t rows4 = (size_t)B * L * ndir * H / 4;
+  if (dtype == MTS_F32)
+    hipLaunchKernelGGL(lstm_hprev_kernel<float>, dim3((unsigned)((rows4 + 255) / 256)), dim3(256), 0, st, B, L, H, ndir, lengths, (const float*)out, (float*)hprev);
+  else
+    hipLaunchKernelGGL(lstm_hprev_kernel<bf16_t>, dim3((unsigned)((rows4 + 255) / 256)), dim3(256), 0, st, B, L, H, ndir, lengths, (const bf16_t*)out,
+                       (bf16_t*)hprev);
+  MTS_LAUNCH_CHECK("mts_lstm_bwd(hprev)");
+  return MTS_OK;
+}
+
 int mts_lstm_pair_bwd(hipStream_t st, int B, int L, int H, int ndir, const float* w_hh, const int32_t* lengths, const void* out, const void* gates,
                       const float* cells, const void* dout, void* dxproj, void* hprev, void* ws) {
   constexpr int KS = 8;
@@ -1100,8 +1113,9 @@ int mts_lstm_pair_bwd(hipStream_t st, int B, int L, int H, int ndir, const float
   }
   if (hipMemsetAsync(xch, 0, pair_xbytes(B, ndir) + 256, st) != hipSuccess) { mts_set_error("lstm_pair: memset failed"); return MTS_ERR_LAUNCH; }
   const size_t rows4 = (size_t)B * L * ndir * H / 4;
-  hipLaunchKernelGGL(lstm_hprev_kernel<bf16_t>, dim3((unsigned)((rows4 + 255) / 256)), dim3(256), 0, st, B, L, H, ndir, lengths, (const bf16_t*)out,
-                     (bf16_t*)hprev);
+  if (hprev)      // (NULL: the caller launches mts_lstm_pair_hprev itself, off the recurrence's stream: mts_lstm_bwd_recurrence / _whh)
+    hipLaunchKernelGGL(lstm_hprev_kernel<bf16_t>, dim3((unsigned)((rows4 + 255) / 256)), dim3(256), 0, st, B, L, H, ndir, lengths, (const bf16_t*)out,
+                       (bf16_t*)hprev);
   if (quad) {
     if (int rc = lp_ensure_sticky()) return rc;
     const size_t ldsq = (size_t)2 * LP_DOCS * ((4 * (H / 4) + 8) * 2);
@@ -1566,7 +1580,7 @@ int mts_lstm_quad_f32_bwd(hipStream_t st, int B, int L, int H, int ndir, const f
   float* wpk; u64* xch; unsigned* status;
   if (int rc = quad_f32_common(st, B, H, ndir, w_hh, ws, 1, &wpk, &xch, &status)) return rc;
   const size_t rows4 = (size_t)B * L * ndir * H / 4;
-  hipLaunchKernelGGL(lstm_hprev_kernel<float>, dim3((unsigned)((rows4 + 255) / 256)), dim3(256), 0, st, B, L, H, ndir, lengths, (const float*)out, (float*)hprev);
+  if (hprev) hipLaunchKernelGGL(lstm_hprev_kernel<float>, dim3((unsigned)((rows4 + 255) / 256)), dim3(256), 0, st, B, L, H, ndir, lengths, (const float*)out, (float*)hprev);
   const size_t lds = (size_t)2 * LP_DOCS * (4 * (H / 4) + 4) * 4;
   const int max_quads = std::max(1, std::min(LQ_MAX_QUADS, g_max_pairs / 2));
   const int docs_per_launch = std::max(1, max_quads / ndir) * LP_DOCS;

@@ -319,8 +319,8 @@ def head_bwd_data(dscores, w, dx, accumulate=False):
                                 dx.stride(0), int(accumulate)))
 
 
-def lstm_workspace(dtype, B, Lq, H, ndir, device):
-    return _scratch(lib.mts_lstm_workspace(dtype_code(dtype), B, Lq, H, ndir), device, 'lstm')
+def lstm_workspace(dtype, B, Lq, H, ndir, device, tag='lstm'):
+    return _scratch(lib.mts_lstm_workspace(dtype_code(dtype), B, Lq, H, ndir), device, tag)
 
 
 def lstm_fwd(xproj, w_hh, b_hh, lengths, B, Lq, H, ndir, out, gates, cells):
@@ -364,3 +364,14 @@ def scale_(x, scale):
         assert x.dtype == torch.float32 and x.is_contiguous()
         check(lib.mts_scale(stream_ptr(), x.numel(), ptr(x), float(scale)))
     return x
+
+
+def lstm_bwd_recurrence(w_hh, lengths, out, gates, cells, dout, B, Lq, H, ndir, dxproj, ws):
+    """first half of lstm_bwd (the recurrence); ws: a workspace of lstm_workspace() size that lstm_bwd_whh gets again, untouched"""
+    check(lib.mts_lstm_bwd_recurrence(stream_ptr(), dtype_code(out.dtype), B, Lq, H, ndir, ptr(w_hh), ptr(lengths), ptr(out), ptr(gates),
+                                      ptr(cells), ptr(dout), ptr(dxproj), ptr(ws)))
+
+
+def lstm_bwd_whh(lengths, out, dxproj, B, Lq, H, ndir, dw_hh, ws):
+    """second half: h_{t-1} and dW_hh (any stream that is ordered behind the recurrence)"""
+    check(lib.mts_lstm_bwd_whh(stream_ptr(), dtype_code(out.dtype), B, Lq, H, ndir, ptr(lengths), ptr(out), ptr(dxproj), ptr(dw_hh), ptr(ws)))

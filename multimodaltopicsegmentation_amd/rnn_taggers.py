@@ -5,6 +5,7 @@ Reference: models/NeuralArchitectures.py:23-145 (RNN), models/CRF.py:274-369 (Bi
 one composes RNN -> CRF the way the reference evidently intended).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -103,11 +104,26 @@ class _RnnStack:
             h = out
         return h, saved
 
-    overlap_wgrad = True     # layers above the first: input-weight gradient + bias column sums on a side stream, under the NEXT layer's
-                             # backward recurrence (which occupies 32 of the 256 CUs and is pure dependent-step latency)
+    overlap_wgrad = True     # every layer's parameter gradients on side streams, off the chain of dependent launches: the recurrence occupies
+                             # 32 of the 256 CUs and is pure dependent-step latency, and what follows it on the critical path is ONE data-
+                             # gradient GEMM -- h_{t-1} + dW_hh (two split-K GEMMs and their reduces, ~80 us per layer at 64 x 256, H = 256) and
+                             # the bias sums + dW_ih (~140 us) wait for nobody until the optimizer.  Round 3 kept dW_hh behind every recurrence
+                             # on the main stream (inside mts_lstm_bwd) and ran layer 0's gradients, all of them, after its recurrence, one
+                             # after the other: 3.06 -> 2.9 ms per BiLSTM step with the two chains side by side (mts_lstm_bwd_recurrence / _whh)
 
-    def _wg_stream(self, dev):
-        return ops.side_stream(dev, 2 if self.tag == 'r2' else 1)       # (late fusion: one per encoder; pool stream 0 is the second encoder's)
+    # Measured on one box (profiles/r04_rnn_overlap_modes.txt; ms per step, BiLSTM 64 x 256 | late fusion 64 x 512):
+    #   0 everything on the issuing stream 3.126 | 7.27     1 both chains on ONE side stream 3.029 | 7.83     2 two chains, two streams 3.002 | 8.11
+    #   3 dW_hh on the issuing stream, the rest on a side stream 3.081 | 8.11         4 as 3 for the layers above the first only (round 3) 3.06 | 7.17
+    # The chains do not come for free: next to a recurrence the 128-tile dW_hh GEMMs take 61 us instead of 25 and the recurrence 663 us instead of
+    # 639 (profiles/r04_v2_bilstm_kernel_stats.csv) -- both poll / stream through the same L2s.  One encoder: 2.  Late fusion runs its second
+    # encoder beside the first already; every further stream costs it more than it hides: 4.
+    overlap_mode = None if os.environ.get('MTS_RNN_OVERLAP') is None else int(os.environ['MTS_RNN_OVERLAP'])
+
+    def _wg_streams(self, dev):
+        """(dW_hh chain, bias + dW_ih chain): two of the small shared pool of side streams per encoder (late fusion: pool stream 0 is the
+        second encoder's own)"""
+        base = 2 if self.tag == 'r2' else 1
+        return ops.side_stream(dev, base), ops.side_stream(dev, base + 2)
 
     def backward(self, saved, dout, lengths_i32, B, Lq):
         o, H = self.o, self.H
@@ -118,22 +134,34 @@ class _RnnStack:
         cur = torch.cuda.current_stream(dev) if dev.type == 'cuda' else None
         # not under a data-parallel hook: with RCCL's streams and late fusion's second encoder stream in the process two more streams
         # made the step slower, not faster (one-rank RCCL run at 64 x 512: 8.69 ms against 7.75 without them; 7.56 / 7.74 without a hook)
-        side = self._wg_stream(dev) if (self.overlap_wgrad and o._grad_hook is None and cur is not None and self.nl > 1) else None
-        used_side = False
+        mode = self.overlap_mode if self.overlap_mode is not None else (4 if hasattr(o, '_rnn2') else 2)
+        if not (self.overlap_wgrad and o._grad_hook is None and cur is not None) or (mode == 4 and self.nl < 2):
+            mode = 0
+        sides = self._wg_streams(dev) if mode else None
         for k in range(self.nl - 1, -1, -1):
             S = saved[k]
             din = S['hin'].shape[1]
             w_hh = o._wspan(pf, *self._names('weight_hh', k), 8 * H, H)
-            # one buffer PER LAYER: layer k's weight gradient and bias sums read its dxproj on the side stream, and nothing on the main
+            # one buffer PER LAYER: layer k's weight gradient and bias sums read its dxproj on the side streams, and nothing on the main
             # stream waits for them before the loop ends -- a buffer shared by layers k and k - 2 (two buffers, as this was) is rewritten by
             # layer k - 2's recurrence with only "a recurrence outlasts a GEMM" in between (silent corruption at >= 3 layers)
             dxproj = o._ws.get(f'{self.tag}dxproj{k}', N, 8 * H, dt, dev)
-            off, n = lay.span(*self._names('weight_hh', k))
-            ops.lstm_bwd(w_hh, lengths_i32, S['out'], S['gates'], S['cells'], dout, B, Lq, H, 2, dxproj, g[off:off + n])
-            if k > 0:                                                              # the critical path first: what the next recurrence needs
+            # ... and one recurrence workspace per layer: mts_lstm_bwd_whh finds (or builds) h_{t-1} in it and takes its split-K slabs from it
+            # while the next layer's recurrence is already running
+            ws = ops.lstm_workspace(dt, B, Lq, H, 2, dev, tag=f'{self.tag}lstm{k}')
+            off_hh, n_hh = lay.span(*self._names('weight_hh', k))
+            ops.lstm_bwd_recurrence(w_hh, lengths_i32, S['out'], S['gates'], S['cells'], dout, B, Lq, H, 2, dxproj, ws)
+            ev = None
+            if sides is not None:
+                ev = torch.cuda.Event()
+                ev.record(cur)                         # dxproj of layer k is complete on the issuing stream
+            if k > 0:                                  # the critical path first: what the next recurrence needs
                 dprev = o._ws.get(f'{self.tag}dprev{k & 1}', N, din, dt, dev)
                 ops.linear_dgrad(dxproj, o._wspan(wf, *self._names('weight_ih', k), 8 * H, din), dprev)
                 dout = dprev
+
+            def whh_of_layer():
+                ops.lstm_bwd_whh(lengths_i32, S['out'], dxproj, B, Lq, H, 2, g[off_hh:off_hh + n_hh], ws)
 
             def params_of_layer():
                 off, n = lay.span(*self._names('bias_ih', k))
@@ -142,22 +170,34 @@ class _RnnStack:
                 g[off2:off2 + n2].copy_(g[off:off + n])
                 off, n = lay.span(*self._names('weight_ih', k))
                 ops.linear_wgrad(dxproj, S['hin'], g[off:off + n].view(8 * H, din))
+
+            if mode == 2:                              # two chains, two streams
+                for side, fn in zip(sides, (whh_of_layer, params_of_layer)):
+                    side.wait_event(ev)
+                    with torch.cuda.stream(side):
+                        fn()
+            elif mode == 1:                            # one side stream, both chains one after the other
+                sides[0].wait_event(ev)
+                with torch.cuda.stream(sides[0]):
+                    whh_of_layer()
+                    params_of_layer()
+            elif mode == 3 or (mode == 4 and k > 0):   # dW_hh behind the data gradient on the main stream, the rest on a side stream
+                whh_of_layer()                         # (4: only for the layers above the first -- round 3's arrangement)
+                sides[0].wait_event(ev)
+                with torch.cuda.stream(sides[0]):
+                    params_of_layer()
+            else:
+                whh_of_layer()
+                params_of_layer()
                 # layer k's parameters (both directions: W_ih, W_hh, b_ih, b_hh are adjacent groups) are final: a data-parallel
                 # trainer may start reducing them while the lower layers' recurrences still run (announced from the stream that
                 # produced them: the collective is ordered behind it)
                 a0 = lay.entries[self._names('weight_ih', k)[0]][0]
                 b0, bn = lay.span(*self._names('bias_hh', k))
                 o._grads_ready(a0, b0 + bn)
-
-            if side is not None and k > 0:
-                side.wait_stream(cur)                  # dxproj of layer k and dW_hh are complete on the issuing stream
-                with torch.cuda.stream(side):
-                    params_of_layer()
-                used_side = True
-            else:
-                params_of_layer()
-        if used_side:
-            cur.wait_stream(side)                      # every gradient has landed before the caller (optimizer, exchange waits) goes on
+        if sides is not None:
+            for side in sides:
+                cur.wait_stream(side)                  # every gradient has landed before the caller (optimizer, exchange waits) goes on
 
 
 class _RnnTaggerBase(_TaggerBase):

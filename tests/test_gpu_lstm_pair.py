@@ -181,3 +181,42 @@ def test_two_concurrent_pair_grids_on_two_streams():
     torch.cuda.synchronize()
     L.check_async()
     assert torch.equal(bufs[0]['out'], ref_a[0]) and torch.equal(bufs[1]['out'], ref_b[0])
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float32], ids=['bf16', 'fp32'])
+@pytest.mark.parametrize('H', [256, 32, 64], ids=['quad', 'generic', 'mfma_or_generic'])
+def test_backward_in_two_calls_equals_the_single_call(H, dt):
+    """mts_lstm_bwd_recurrence + mts_lstm_bwd_whh (the second on ANOTHER stream, behind an event, as the recurrent taggers issue them) against
+    mts_lstm_bwd: dxproj and dW_hh bit for bit, on every recurrence path (CU-quad at H = 256; the kernels that build h_{t-1} themselves below)."""
+    from multimodaltopicsegmentation_amd import ops
+    B, Lq = 19, 23
+    g = torch.Generator().manual_seed(5)
+    lengths = torch.randint(1, Lq + 1, (B,), generator=g)
+    lengths[0] = Lq
+    N = B * Lq
+    xd = _rnd(N, 8 * H, seed=1).to(dt).to(DEV)
+    wd = _rnd(2, 4 * H, H, seed=2, scale=1 / math.sqrt(H)).to(DEV)
+    bd = _rnd(2, 4 * H, seed=3, scale=0.1).to(DEV)
+    dd = _rnd(N, 2 * H, seed=4).to(dt).to(DEV)
+    li32 = lengths.to(torch.int32).to(DEV)
+    out = torch.empty(N, 2 * H, dtype=dt, device=DEV)
+    gates = torch.empty(N, 8 * H, dtype=dt, device=DEV)
+    cells = torch.empty(N, 2 * H, device=DEV)
+    ops.lstm_fwd(xd, wd, bd, li32, B, Lq, H, 2, out, gates, cells)
+    dxp1 = torch.full((N, 8 * H), float('nan'), dtype=dt, device=DEV)
+    dw1 = torch.full((2, 4 * H, H), float('nan'), device=DEV)
+    ops.lstm_bwd(wd, li32, out, gates, cells, dd, B, Lq, H, 2, dxp1, dw1)
+    dxp2 = torch.full((N, 8 * H), float('nan'), dtype=dt, device=DEV)
+    dw2 = torch.full((2, 4 * H, H), float('nan'), device=DEV)
+    ws = ops.lstm_workspace(dt, B, Lq, H, 2, DEV, tag='test_split')
+    ops.lstm_bwd_recurrence(wd, li32, out, gates, cells, dd, B, Lq, H, 2, dxp2, ws)
+    ev = torch.cuda.Event()
+    ev.record()
+    side = torch.cuda.Stream()
+    side.wait_event(ev)
+    with torch.cuda.stream(side):
+        ops.lstm_bwd_whh(li32, out, dxp2, B, Lq, H, 2, dw2, ws)
+    torch.cuda.synchronize()
+    view = torch.int16 if dt == torch.bfloat16 else torch.int32
+    assert torch.equal(dxp1.view(view), dxp2.view(view))
+    assert torch.equal(dw1.view(torch.int32), dw2.view(torch.int32)) and not torch.isnan(dw2).any()

@@ -277,9 +277,11 @@ def test_state_dict_roundtrip_and_dead_keys():
 
 
 # ------------------------------------------------------------------------------------------------ data-parallel overlap (row e)
-def test_gradient_ready_spans_are_final_disjoint_and_cover_every_gradient():
+@pytest.mark.parametrize('release', ['block', 'projection'])
+def test_gradient_ready_spans_are_final_disjoint_and_cover_every_gradient(release):
     """trainer.NativeTrainer starts the RCCL all-reduce of a flat-gradient span from inside the backward: every span
-    handed to the hook must already hold its final value, spans must not overlap, and nothing outside them may be non-zero."""
+    handed to the hook must already hold its final value, spans must not overlap, and nothing outside them may be non-zero.  Both ways of
+    releasing the q | k | v block: whole, behind ONE weight-gradient GEMM (the default), or per projection (three GEMMs)."""
     from multimodaltopicsegmentation_amd.taggers import Transformer_segmenter
     B, L, D = 3, 24, 64
     m = Transformer_segmenter(2, D, 32, num_layers=3, nheads=4, loss_fn='FocalLoss', window_size=4, compute_dtype='fp32',
@@ -289,6 +291,7 @@ def test_gradient_ready_spans_are_final_disjoint_and_cover_every_gradient():
     y = (torch.rand(B, L, generator=g) < 0.3).float().to(DEV)
     lengths = torch.tensor([24, 17, 9])
     seen = []
+    m.qkv_release = release
     m._grad_hook = lambda a, b: seen.append((a, b, m.grad_flat()[a:b].clone()))
     m.loss_and_grad(x, lengths, y, True)
     m._grad_hook = None
@@ -299,8 +302,8 @@ def test_gradient_ready_spans_are_final_disjoint_and_cover_every_gradient():
         covered[a:b] += 1
     assert int(covered.max()) == 1
     assert torch.count_nonzero(final.cpu()[covered == 0]) == 0
-    assert len(seen) == 4 * 3 + 2                         # per layer: tail block + one span per q / k / v projection (the last with the
-                                                          # three biases); embeddings: positions + rest
+    # per layer: tail block + the q | k | v block (one span, or one per projection, the last with the three biases); embeddings: positions + rest
+    assert len(seen) == (4 if release == 'projection' else 2) * 3 + 2
     assert torch.count_nonzero(final) > 0.9 * int(covered.sum())
 
 

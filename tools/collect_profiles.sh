@@ -31,8 +31,9 @@ echo "[6b] the N > 1 step path on one GPU: one-rank RCCL group, overlapped excha
 MTS_BENCH_SINGLE_RANK_DP=1 python3 bench.py $B --sustained-steps 200 > $OUT/bench_dp1.json 2> /dev/null
 MTS_BENCH_SINGLE_RANK_DP=1 python3 bench.py --arch latefusion --seq 512 --steps 10 --warmup 3 $B --sustained-steps 100 > $OUT/bench_dp1_latefusion512.json 2> /dev/null
 MTS_BENCH_SINGLE_RANK_DP=1 MTS_DP_SCHEDULE=rs_ag python3 bench.py $B --sustained-steps 200 > $OUT/bench_dp1_rs_ag.json 2> /dev/null
+MTS_BENCH_SINGLE_RANK_DP=1 MTS_DP_QKV_RELEASE=projection python3 bench.py $B --sustained-steps 200 > $OUT/bench_dp1_projection.json 2> /dev/null
 echo "[6c] host batches in the loop (PCIe-inclusive variant lines)"
-for m in "pinned fp32" "pageable fp32" "pinned bf16"; do set -- $m; python3 bench.py --h2d $1 --h2d-wire $2 $B 2> /dev/null; done > $OUT/h2d.jsonl
+for m in "pinned fp32" "pageable fp32" "pinned bf16" "collater fp32" "collater bf16"; do set -- $m; python3 bench.py --h2d $1 --h2d-wire $2 $B 2> /dev/null; done > $OUT/h2d.jsonl
 echo "[7] fp32 (parity) mode throughput"
 python3 bench.py --dtype fp32 --steps 5 --warmup 2 $B --sustained-steps 0 > $OUT/bench_fp32.json 2> /dev/null
 python3 bench.py --dtype fp32 --arch bilstm --steps 5 --warmup 2 $B --sustained-steps 0 > $OUT/bench_fp32_bilstm.json 2> /dev/null
@@ -41,4 +42,8 @@ echo "[8] in-process A/B lines"
 python3 tools/band_ab.py > $OUT/band_fused_ab.txt 2> /dev/null
 MTS_B=16 MTS_L=1024 python3 tools/band_ab.py >> $OUT/band_fused_ab.txt 2> /dev/null
 bash tools/step_ab.sh "band_fused_bwd=0" "band_fused_bwd=1" > $OUT/step_ab_band.txt 2> /dev/null
+echo "[9] GEMMs against the vendor library and against the kernels they replace, one process each"
+python3 tools/blas_compare.py > $OUT/gemm_vs_vendor.txt 2>&1
+python3 tools/gemm_ab.py gemm_variant 0 9 6 > $OUT/gemm_ab.txt 2>&1
+python3 tools/tn_sweep.py > $OUT/tn_sweep.txt 2>&1
 echo done
