@@ -703,14 +703,14 @@ static int launch_one(const GemmArgs& a, int splits, hipStream_t st) {
   }
 }
 
-int mts_launch_gemm224r(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st);   // gemm224r.hip: four-wave register-staged form
+int mts_launch_gemm224r(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st);   // gemm224r.hip: four-wave NT form, one tile per workgroup (gemm_bf16_224d_kernel)
 int mts_launch_gemm224t(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st);   // gemm224t.hip: four-wave weight-gradient (TN) form
 int mts_launch_gemm224p(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st);   // gemm224p.hip: four-wave persistent forward (NT) form
 
 // called from mts_gemm (gemm.hip) when N is a multiple of 224 and the 224-wide tiling fills the CUs better
 int mts_launch_gemm224(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st) {
-  // bf16 C, NT (the forward projections): the four-wave kernel with buffer-load LDS-DMA (gemm224r.hip, gemm_bf16_224d_kernel) where it applies --
-  // bitwise the same results, 4 % faster back to back on the step's shapes, 8-10 % at deep K.  gemm_variant 6 keeps the eight-wave kernel (A/B).
+  // bf16 C, NT (the forward projections): the four-wave kernels with buffer-load LDS-DMA where they apply -- persistent (gemm224p.hip, the default)
+  // or one tile per workgroup (gemm224r.hip, gemm_variant 9); bitwise the results of the eight-wave kernel, which gemm_variant 6 keeps (A/B).
   if (a.variant == 0 && !c_is_f32 && layout == MTS_NT && splits == 1) {
     int rc = mts_launch_gemm224p(a, layout, c_is_f32, splits, st);          // persistent form (gemm224p.hip); gemm_variant 9: one tile per workgroup
     if (rc >= 0) return rc;
@@ -724,7 +724,7 @@ int mts_launch_gemm224(const GemmArgs& a, int layout, bool c_is_f32, int splits,
     const int rc = mts_launch_gemm224t(a, layout, c_is_f32, splits, st);
     if (rc >= 0) return rc;
   }
-  if (a.variant == 7 || a.variant == 8 || a.variant == 9 || (a.variant >= 71 && a.variant <= 79)) {                       // A/B: the four-wave register-staged kernels where they apply
+  if (a.variant == 9) {                                   // A/B: the one-tile-per-workgroup four-wave kernel where it applies
     const int rc = mts_launch_gemm224r(a, layout, c_is_f32, splits, st);
     if (rc >= 0) return rc;
   }

@@ -228,6 +228,26 @@ int mts_lstm_quad_f32_bwd(hipStream_t st, int B, int L, int H, int ndir, const f
                           const float* cells, const void* dout, void* dxproj, void* hprev, void* ws);
 unsigned mts_lstm_pair_take_error();                  // lstm_pair.hip: sticky timeout word (pinned host memory), reading clears
 static thread_local int g_lstm_mfma = 1;
+void mts_lstm_pair_force_parts(int n);      // lstm_pair.hip
+int mts_lstm_pair_parts();
+// Which recurrence form wrote a saved state, keyed by its `out` buffer.  The form fixes the layout of the opaque gates / cells and who produces
+// h_{t-1}; it follows from options that are per host thread ("lstm_mfma", "lstm_parts"), and torch's autograd runs backward nodes on a thread of
+// its own: the backward FOLLOWS what the forward recorded instead of re-reading its own thread's options.  0: the generic / MFMA
+// kernels ([B*L, ndir*4H] gates), 2: CU pair, 4: CU quad (step-major blocks).  A few hundred entries at most (one per live `out` buffer).
+#include <mutex>
+#include <unordered_map>
+static std::mutex g_form_mu;
+static std::unordered_map<const void*, int> g_form;
+static void lstm_form_note(const void* out, int form) {
+  std::lock_guard<std::mutex> lk(g_form_mu);
+  if (g_form.size() > 4096) g_form.clear();
+  g_form[out] = form;
+}
+static int lstm_form_of(const void* out) {
+  std::lock_guard<std::mutex> lk(g_form_mu);
+  auto it = g_form.find(out);
+  return it == g_form.end() ? -1 : it->second;
+}
 
 // Asynchronous device-side errors, reported without synchronising: today the only source is a CU-pair LSTM launch whose partner
 // poll gave up.  Every mts_lstm_* entry calls this first, so the error surfaces at the next step at the latest.
@@ -269,9 +289,12 @@ extern "C" int mts_lstm_fwd(void* stream, int dtype, int B, int L, int H, int nd
   MTS_UNSUPPORTED(H <= 1024, "mts_lstm_fwd: hidden size %d > 1024", H);
   if (int rc = lstm_report_async("mts_lstm_fwd")) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (g_lstm_mfma && mts_lstm_pair_supported(dtype, H))
+  if (g_lstm_mfma && mts_lstm_pair_supported(dtype, H)) {
+    lstm_form_note(out, mts_lstm_pair_parts());
     return dtype == MTS_F32 ? mts_lstm_quad_f32_fwd(st, B, L, H, ndir, xproj, w_hh, b_hh, lengths, out, gates, cells, workspace)
                             : mts_lstm_pair_fwd(st, B, L, H, ndir, xproj, w_hh, b_hh, lengths, out, gates, cells, workspace);
+  }
+  lstm_form_note(out, 0);
   if (g_lstm_mfma && mts_lstm_mfma_supported(dtype, H))
     return mts_lstm_mfma_fwd(st, B, L, H, ndir, xproj, w_hh, b_hh, lengths, out, gates, cells, workspace);
   float* whhT = (float*)workspace;
@@ -300,8 +323,11 @@ static int lstm_bwd_impl(int part, void* stream, int dtype, int B, int L, int H,
   hipStream_t st = (hipStream_t)stream;
   const size_t hoff = lstm_scratch_bytes(B, H, ndir);
   char* hprev = (char*)workspace + hoff;
-  const bool pairq = g_lstm_mfma && mts_lstm_pair_supported(dtype, H);
-  const bool fast = g_lstm_mfma && (mts_lstm_mfma_supported(dtype, H) || pairq);
+  // the form the forward recorded for this saved state wins over the calling thread's options (see lstm_form_note)
+  const int form = lstm_form_of(out);
+  struct ForceParts { ForceParts(int f) { mts_lstm_pair_force_parts(f); } ~ForceParts() { mts_lstm_pair_force_parts(0); } } force_parts(form > 0 ? form : 0);
+  const bool pairq = form >= 0 ? form > 0 : (g_lstm_mfma && mts_lstm_pair_supported(dtype, H));
+  const bool fast = pairq || (g_lstm_mfma && mts_lstm_mfma_supported(dtype, H));
   if (part & 1) {
     if (fast) {
       // the CU-pair / CU-quad recurrences take h_{t-1} from a kernel of its own: with the recurrence when both parts run here, otherwise with part 2

@@ -353,8 +353,12 @@ unsigned mts_lstm_pair_take_error() {
   return v;
 }
 
-static thread_local int g_lstm_parts = 4;          // mts_set_option("lstm_parts", 2 | 4): CU pair or CU quad form of the recurrences
-void mts_lstm_pair_set_parts(int n) { g_lstm_parts = (n == 2) ? 2 : 4; }
+static thread_local int g_lstm_parts_opt = 4;      // mts_set_option("lstm_parts", 2 | 4): CU pair or CU quad form of the recurrences
+static thread_local int g_lstm_parts_forced = 0;   // 2 | 4 while a backward call follows the form its forward recorded (lstm.hip), else 0
+#define g_lstm_parts (g_lstm_parts_forced ? g_lstm_parts_forced : g_lstm_parts_opt)
+void mts_lstm_pair_set_parts(int n) { g_lstm_parts_opt = (n == 2) ? 2 : 4; }
+void mts_lstm_pair_force_parts(int n) { g_lstm_parts_forced = (n == 2 || n == 4) ? n : 0; }
+int mts_lstm_pair_parts() { return g_lstm_parts; }
 bool mts_lstm_pair_supported(int dtype, int H) {
   if (g_pair_mode < 0) { const char* e = getenv("MTS_LSTM_PAIR"); g_pair_mode = (e && e[0] == '0') ? 0 : 1; }
   // fp32 (parity mode): only the CU-quad form exists (W_hh in fp32 is 256 registers per lane of a quad's waves)

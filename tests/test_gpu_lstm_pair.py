@@ -220,3 +220,44 @@ def test_backward_in_two_calls_equals_the_single_call(H, dt):
     view = torch.int16 if dt == torch.bfloat16 else torch.int32
     assert torch.equal(dxp1.view(view), dxp2.view(view))
     assert torch.equal(dw1.view(torch.int32), dw2.view(torch.int32)) and not torch.isnan(dw2).any()
+
+
+def test_backward_on_another_host_thread_follows_the_forwards_recurrence_form():
+    """The tuning switches are per host thread and torch's autograd runs backward nodes on a thread of its own: a forward under
+    mts_set_option("lstm_parts", 2) (CU-pair form: its own layout of the saved gates / cells) followed by mts_lstm_bwd from a thread whose
+    switches are the defaults (CU quad) must still read the state in the form it was written -- the library records the form per saved
+    state.  Same bits as the backward issued from the forward's thread."""
+    import threading
+    from multimodaltopicsegmentation_amd import _lib as L, ops
+    B, Lq, H, dt = 18, 21, 256, torch.bfloat16
+    lengths = torch.randint(1, Lq + 1, (B,), generator=torch.Generator().manual_seed(9))
+    lengths[0] = Lq
+    N = B * Lq
+    xd = _rnd(N, 8 * H, seed=1).to(dt).to(DEV)
+    wd = _rnd(2, 4 * H, H, seed=2, scale=1 / math.sqrt(H)).to(DEV)
+    bd = _rnd(2, 4 * H, seed=3, scale=0.1).to(DEV)
+    dd = _rnd(N, 2 * H, seed=4).to(dt).to(DEV)
+    li32 = lengths.to(torch.int32).to(DEV)
+    out = torch.empty(N, 2 * H, dtype=dt, device=DEV)
+    gates = torch.empty(N, 8 * H, dtype=dt, device=DEV)
+    cells = torch.empty(N, 2 * H, device=DEV)
+    res = {}
+
+    def bwd(tag):
+        dxp = torch.full((N, 8 * H), float('nan'), dtype=dt, device=DEV)
+        dw = torch.empty(2, 4 * H, H, device=DEV)
+        ops.lstm_bwd(wd, li32, out, gates, cells, dd, B, Lq, H, 2, dxp, dw)
+        torch.cuda.synchronize()
+        res[tag] = (dxp, dw)
+    try:
+        L.check(L.lib.mts_set_option(b'lstm_parts', 2))
+        ops.lstm_fwd(xd, wd, bd, li32, B, Lq, H, 2, out, gates, cells)
+        bwd('same thread')
+        th = threading.Thread(target=bwd, args=('other thread',))
+        th.start()
+        th.join()
+    finally:
+        L.check(L.lib.mts_set_option(b'lstm_parts', 4))
+    assert torch.equal(res['same thread'][0].view(torch.int16), res['other thread'][0].view(torch.int16))
+    assert torch.equal(res['same thread'][1].view(torch.int32), res['other thread'][1].view(torch.int32))
+    assert not torch.isnan(res['other thread'][0].float()).any()
