@@ -329,8 +329,9 @@ def lstm_fwd(xproj, w_hh, b_hh, lengths, B, Lq, H, ndir, out, gates, cells):
                            ptr(gates), ptr(cells), ptr(ws)))
 
 
-def lstm_bwd(w_hh, lengths, out, gates, cells, dout, B, Lq, H, ndir, dxproj, dw_hh):
-    ws = lstm_workspace(out.dtype, B, Lq, H, ndir, out.device)
+def lstm_bwd(w_hh, lengths, out, gates, cells, dout, B, Lq, H, ndir, dxproj, dw_hh, ws=None):
+    if ws is None:
+        ws = lstm_workspace(out.dtype, B, Lq, H, ndir, out.device)
     check(lib.mts_lstm_bwd(stream_ptr(), dtype_code(out.dtype), B, Lq, H, ndir, ptr(w_hh), ptr(lengths), ptr(out), ptr(gates),
                            ptr(cells), ptr(dout), ptr(dxproj), ptr(dw_hh), ptr(ws)))
 

@@ -109,21 +109,24 @@ class _RnnStack:
                              # gradient GEMM -- h_{t-1} + dW_hh (two split-K GEMMs and their reduces, ~80 us per layer at 64 x 256, H = 256) and
                              # the bias sums + dW_ih (~140 us) wait for nobody until the optimizer.  Round 3 kept dW_hh behind every recurrence
                              # on the main stream (inside mts_lstm_bwd) and ran layer 0's gradients, all of them, after its recurrence, one
-                             # after the other: 3.06 -> 2.9 ms per BiLSTM step with the two chains side by side (mts_lstm_bwd_recurrence / _whh)
+                             # after the other (mts_lstm_bwd_recurrence / _whh split the call; which arrangement: overlap_mode below)
 
-    # Measured on one box (profiles/r04_rnn_overlap_modes.txt; ms per step, BiLSTM 64 x 256 | late fusion 64 x 512):
-    #   0 everything on the issuing stream 3.126 | 7.27     1 both chains on ONE side stream 3.029 | 7.83     2 two chains, two streams 3.002 | 8.11
-    #   3 dW_hh on the issuing stream, the rest on a side stream 3.081 | 8.11         4 as 3 for the layers above the first only (round 3) 3.06 | 7.17
-    # The chains do not come for free: next to a recurrence the 128-tile dW_hh GEMMs take 61 us instead of 25 and the recurrence 663 us instead of
-    # 639 (profiles/r04_v2_bilstm_kernel_stats.csv) -- both poll / stream through the same L2s.  One encoder: 2.  Late fusion runs its second
-    # encoder beside the first already; every further stream costs it more than it hides: 4.
+    # Measured, one box per table (profiles/r04_rnn_overlap_modes.txt; ms per step, BiLSTM 64 x 256 | late fusion 64 x 512):
+    #   0 everything on the issuing stream                                            3.087 | 7.24
+    #   1 both chains (h_{t-1} + dW_hh, then bias sums + dW_ih) on ONE side stream    3.014 | 7.07      <- default
+    #   2 the two chains on two side streams                                          3.020 | 8.0 (its two extra streams crowd the hardware queues)
+    #   3 dW_hh on the issuing stream behind the data gradient, the rest on a side stream   3.068 | 7.21
+    #   4 as 3, layers above the first only; 5 round 3 call for call (h_{t-1} in front of the recurrence, dW_hh behind it, on the issuing stream)   3.087 | 7.24, 7.20
+    # The chains do not come for free: next to a recurrence the 128-tile dW_hh GEMMs take 61 us instead of 25 and the recurrence 663 us instead
+    # of 639 (rocprofv3 of modes 0 / 2) -- both poll / stream through the same L2s.
     overlap_mode = None if os.environ.get('MTS_RNN_OVERLAP') is None else int(os.environ['MTS_RNN_OVERLAP'])
 
-    def _wg_streams(self, dev):
-        """(dW_hh chain, bias + dW_ih chain): two of the small shared pool of side streams per encoder (late fusion: pool stream 0 is the
-        second encoder's own)"""
+    def _wg_streams(self, dev, n):
+        """n (1 | 2) of the small shared pool of side streams for this encoder: the dW_hh chain's and the bias + dW_ih chain's (late fusion: pool
+        stream 0 is the second encoder's own).  Only the streams a mode USES are created: HIP hands its hardware queues out in creation order, and
+        two unused streams of the pool in front of the ones that matter moved late fusion's encoders onto one queue (8.2 against 7.2 ms)."""
         base = 2 if self.tag == 'r2' else 1
-        return ops.side_stream(dev, base), ops.side_stream(dev, base + 2)
+        return tuple(ops.side_stream(dev, base + 2 * i) for i in range(n))
 
     def backward(self, saved, dout, lengths_i32, B, Lq):
         o, H = self.o, self.H
@@ -134,10 +137,10 @@ class _RnnStack:
         cur = torch.cuda.current_stream(dev) if dev.type == 'cuda' else None
         # not under a data-parallel hook: with RCCL's streams and late fusion's second encoder stream in the process two more streams
         # made the step slower, not faster (one-rank RCCL run at 64 x 512: 8.69 ms against 7.75 without them; 7.56 / 7.74 without a hook)
-        mode = self.overlap_mode if self.overlap_mode is not None else (4 if hasattr(o, '_rnn2') else 2)
+        mode = self.overlap_mode if self.overlap_mode is not None else 1
         if not (self.overlap_wgrad and o._grad_hook is None and cur is not None) or (mode == 4 and self.nl < 2):
             mode = 0
-        sides = self._wg_streams(dev) if mode else None
+        sides = self._wg_streams(dev, 2 if mode == 2 else 1) if mode else None
         for k in range(self.nl - 1, -1, -1):
             S = saved[k]
             din = S['hin'].shape[1]
@@ -150,7 +153,10 @@ class _RnnStack:
             # while the next layer's recurrence is already running
             ws = ops.lstm_workspace(dt, B, Lq, H, 2, dev, tag=f'{self.tag}lstm{k}')
             off_hh, n_hh = lay.span(*self._names('weight_hh', k))
-            ops.lstm_bwd_recurrence(w_hh, lengths_i32, S['out'], S['gates'], S['cells'], dout, B, Lq, H, 2, dxproj, ws)
+            if mode == 5:                              # round 3, call for call: h_{t-1}, recurrence, dW_hh in ONE call on the issuing stream
+                ops.lstm_bwd(w_hh, lengths_i32, S['out'], S['gates'], S['cells'], dout, B, Lq, H, 2, dxproj, g[off_hh:off_hh + n_hh], ws=ws)
+            else:
+                ops.lstm_bwd_recurrence(w_hh, lengths_i32, S['out'], S['gates'], S['cells'], dout, B, Lq, H, 2, dxproj, ws)
             ev = None
             if sides is not None:
                 ev = torch.cuda.Event()
@@ -180,6 +186,13 @@ class _RnnStack:
                 sides[0].wait_event(ev)
                 with torch.cuda.stream(sides[0]):
                     whh_of_layer()
+                    params_of_layer()
+            elif mode == 5:
+                if k > 0:
+                    sides[0].wait_event(ev)
+                    with torch.cuda.stream(sides[0]):
+                        params_of_layer()
+                else:
                     params_of_layer()
             elif mode == 3 or (mode == 4 and k > 0):   # dW_hh behind the data gradient on the main stream, the rest on a side stream
                 whh_of_layer()                         # (4: only for the layers above the first -- round 3's arrangement)
