@@ -141,6 +141,11 @@ int mts_collate_pad(int src_dtype, int dst_dtype, int B, int Lmax, int D, const 
 int mts_embed_layernorm_fwd(void* stream, int dtype, int B, int L, int D, const float* x, const float* pos,
                             int pos_offset, const float* type0, const float* gamma, const float* beta, float eps,
                             void* y, void* pre, float* mean, float* rstd, const int32_t* row_src, int n_rows);
+/* ... on a batch that arrived in bf16 (x_bf16: bf16 [B, L, D]; bf16 activations; one source): the same bits as mts_embed_layernorm_fwd on the fp32
+ * values of the same numbers, without an fp32 copy of the batch (prefetch.DevicePrefetcher / AudioPortionDataset(wire_dtype='bf16')). */
+int mts_embed_layernorm_fwd_x16(void* stream, int B, int L, int D, const void* x_bf16, const float* pos, int pos_offset, const float* type0,
+                                const float* gamma, const float* beta, float eps, void* y, void* pre, float* mean, float* rstd,
+                                const int32_t* row_src, int n_rows);
 /* ... and the same embedding + LayerNorm as mts_embed_layernorm_fwd on x = x1[b,i,0:D1] | x2[b,i,0:D2] (D = D1 + D2). */
 int mts_embed_layernorm_fwd2(void* stream, int dtype, int B, int L, int D1, int D2, const float* x1, const float* x2, const float* pos,
                              int pos_offset, const float* type0, const float* gamma, const float* beta, float eps,

@@ -56,6 +56,7 @@ SIGNATURES = {
     'mts_cast_concat': (_i, [_vp, _i, _sz, _i, _i, _vp, _vp, _vp]),
     'mts_embed_layernorm_fwd2': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i]),
     'mts_embed_layernorm_fwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i]),
+    'mts_embed_layernorm_fwd_x16': (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i]),
     'mts_layernorm_fwd': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'mts_layernorm_bwd_workspace': (_sz, [_i]),
     'mts_layernorm_bwd': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -57,7 +57,9 @@ template <int NV> __device__ __forceinline__ void row_stats(const float (&x)[NV]
 // ------------------------------------------------------------------------------------------------
 // FULL (D == NV * 256): no per-slot bounds checks, hence no divergent branches around the loads -- behind such a branch the
 // compiler waits for every outstanding load before the next slot (seven serial HBM round trips per row at D = 1792).
-template <typename T, int NV, bool EMBED, bool FULL = false>
+// EMBED: 0 plain LayerNorm; 1 embedding block on fp32 inputs (the collater's batch); 2 the same on bf16 inputs (a batch that crossed PCIe in bf16:
+// prefetch.DevicePrefetcher / AudioPortionDataset(wire_dtype='bf16') -- read as it is, no fp32 copy of it is ever made)
+template <typename T, int NV, int EMBED, bool FULL = false>
 __global__ __launch_bounds__(64 * ROW_WAVES) void ln_fwd_kernel(
     const void* __restrict__ xin, const float* __restrict__ pos, int pos_offset, int L, const float* __restrict__ type0,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int rows, int D,
@@ -82,7 +84,9 @@ __global__ __launch_bounds__(64 * ROW_WAVES) void ln_fwd_kernel(
       const int e = 4 * (lane + 64 * i);
       if (FULL || e < D) {
         float a[4], b[4], c[4];
-        load4<float>((e < Dx ? xr : xr2) + e, a); load4<float>(pr + e, b); load4<float>(type0 + e, c);
+        if constexpr (EMBED == 2) load4<bf16_t>(reinterpret_cast<const bf16_t*>(xin) + (size_t)src * D + e, a);
+        else load4<float>((e < Dx ? xr : xr2) + e, a);
+        load4<float>(pr + e, b); load4<float>(type0 + e, c);
 #pragma unroll
         for (int j = 0; j < 4; ++j) x[i][j] = (a[j] + b[j]) + c[j];   // same association as HF:421
         if constexpr (sizeof(T) == 2) {
@@ -806,7 +810,7 @@ template <typename F> static inline void dispatch_nv8(int nv, F&& f) {   // kern
   }
 }
 
-template <typename T, bool EMBED>
+template <typename T, int EMBED>
 static int ln_fwd_launch(hipStream_t st, const void* x, const float* pos, int pos_offset, int L, const float* type0, const float* gamma,
                          const float* beta, float eps, int rows, int D, void* y, void* pre, float* mean, float* rstd,
                          const float* head_w, const float* head_b, int n_out, float* scores, const int32_t* row_src = nullptr,
@@ -835,10 +839,10 @@ static int embed_ln_fwd(void* stream, int dtype, int B, int L, int D, const floa
   MTS_CHECK_ARG(!x2 || (D1 > 0 && D1 < D && D1 % 4 == 0), "%s: the first part's width must be a multiple of 4 inside (0, D)", who);
   const int rows = row_src ? n_rows : B * L;
   if (dtype == MTS_F32)
-    return ln_fwd_launch<float, true>((hipStream_t)stream, x, pos, pos_offset, L, type0, gamma, beta, eps, rows, D, y, pre, mean, rstd,
+    return ln_fwd_launch<float, 1>((hipStream_t)stream, x, pos, pos_offset, L, type0, gamma, beta, eps, rows, D, y, pre, mean, rstd,
                                       nullptr, nullptr, 0, nullptr, row_src, x2, D1);
   if (dtype == MTS_BF16)
-    return ln_fwd_launch<bf16_t, true>((hipStream_t)stream, x, pos, pos_offset, L, type0, gamma, beta, eps, rows, D, y, pre, mean, rstd,
+    return ln_fwd_launch<bf16_t, 1>((hipStream_t)stream, x, pos, pos_offset, L, type0, gamma, beta, eps, rows, D, y, pre, mean, rstd,
                                        nullptr, nullptr, 0, nullptr, row_src, x2, D1);
   mts_set_error("%s: bad dtype %d", who, dtype);
   return MTS_ERR_INVALID;
@@ -849,6 +853,18 @@ extern "C" int mts_embed_layernorm_fwd(void* stream, int dtype, int B, int L, in
                                        float* mean, float* rstd, const int32_t* row_src, int n_rows) {
   return embed_ln_fwd(stream, dtype, B, L, D, x, nullptr, 0, pos, pos_offset, type0, gamma, beta, eps, y, pre, mean, rstd, row_src, n_rows,
                       "mts_embed_layernorm_fwd");
+}
+
+// the embedding block on a bf16 batch (one source, bf16 activations): bit for bit what mts_embed_layernorm_fwd gives on the fp32 values of the same numbers
+extern "C" int mts_embed_layernorm_fwd_x16(void* stream, int B, int L, int D, const void* x_bf16, const float* pos, int pos_offset, const float* type0,
+                                           const float* gamma, const float* beta, float eps, void* y, void* pre, float* mean, float* rstd,
+                                           const int32_t* row_src, int n_rows) {
+  MTS_CHECK_ARG(B > 0 && L > 0 && D > 0 && x_bf16 && pos && type0 && gamma && beta && y, "mts_embed_layernorm_fwd_x16: bad arguments");
+  MTS_CHECK_ARG(!row_src || (n_rows > 0 && n_rows <= B * L), "mts_embed_layernorm_fwd_x16: packed form needs 0 < n_rows <= B*L");
+  MTS_CHECK_ARG(((uintptr_t)x_bf16 & 7) == 0, "mts_embed_layernorm_fwd_x16: x must be 8-byte aligned");
+  const int rows = row_src ? n_rows : B * L;
+  return ln_fwd_launch<bf16_t, 2>((hipStream_t)stream, x_bf16, pos, pos_offset, L, type0, gamma, beta, eps, rows, D, y, pre, mean, rstd, nullptr, nullptr, 0,
+                                  nullptr, row_src, nullptr, 0);
 }
 
 extern "C" int mts_embed_layernorm_fwd2(void* stream, int dtype, int B, int L, int D1, int D2, const float* x1, const float* x2, const float* pos,
@@ -864,10 +880,10 @@ extern "C" int mts_layernorm_fwd(void* stream, int dtype, int rows, int D, const
   MTS_CHECK_ARG(rows > 0 && D > 0 && x && gamma && beta && (y || (head_w && mean && rstd)), "mts_layernorm_fwd: bad arguments (y may be NULL only with a fused head and saved statistics)");
   MTS_CHECK_ARG(!head_w || (head_b && scores && n_out >= 1 && n_out <= 4), "mts_layernorm_fwd: fused head needs head_b, scores, n_out<=4");
   if (dtype == MTS_F32)
-    return ln_fwd_launch<float, false>((hipStream_t)stream, x, nullptr, 0, 1, nullptr, gamma, beta, eps, rows, D, y, nullptr, mean, rstd,
+    return ln_fwd_launch<float, 0>((hipStream_t)stream, x, nullptr, 0, 1, nullptr, gamma, beta, eps, rows, D, y, nullptr, mean, rstd,
                                        head_w, head_b, n_out, scores);
   if (dtype == MTS_BF16)
-    return ln_fwd_launch<bf16_t, false>((hipStream_t)stream, x, nullptr, 0, 1, nullptr, gamma, beta, eps, rows, D, y, nullptr, mean, rstd,
+    return ln_fwd_launch<bf16_t, 0>((hipStream_t)stream, x, nullptr, 0, 1, nullptr, gamma, beta, eps, rows, D, y, nullptr, mean, rstd,
                                         head_w, head_b, n_out, scores);
   mts_set_error("mts_layernorm_fwd: bad dtype %d", dtype);
   return MTS_ERR_INVALID;

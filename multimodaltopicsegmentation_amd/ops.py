@@ -183,6 +183,11 @@ def embed_layernorm_fwd(x, pos, pos_offset, type0, gamma, beta, eps, y, pre, mea
     """row_src (int32 [n_rows], optional): packed batch -- output row r is sentence row_src[r] = b*L + i of x.
     x2 (fp32 [B, L, D2], optional): K-split input -- the row is x[b, i] | x2[b, i] and the concatenation is never materialised."""
     B, Lq, D = x.shape
+    if x.dtype == torch.bfloat16:
+        assert x2 is None and y.dtype == torch.bfloat16
+        check(lib.mts_embed_layernorm_fwd_x16(stream_ptr(), B, Lq, D, ptr(x), ptr(pos), pos_offset, ptr(type0), ptr(gamma), ptr(beta), eps, ptr(y),
+                                              ptr(pre), ptr(mean), ptr(rstd), ptr(row_src), row_src.numel() if row_src is not None else 0))
+        return
     if x2 is not None:
         check(lib.mts_embed_layernorm_fwd2(stream_ptr(), dtype_code(y.dtype), B, Lq, D, x2.shape[2], ptr(x), ptr(x2), ptr(pos), pos_offset,
                                            ptr(type0), ptr(gamma), ptr(beta), eps, ptr(y), ptr(pre), ptr(mean), ptr(rstd), ptr(row_src),

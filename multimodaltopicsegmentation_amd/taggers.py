@@ -518,7 +518,10 @@ class Transformer_segmenter(_TaggerBase):
         ws, lay = self._ws, self._layout
         wf = self._weights()                  # compute-dtype mirror (GEMM operands)
         pf = self._flat                       # fp32 masters (biases, LayerNorm, embeddings, head)
-        x = xs.contiguous().to(torch.float32)
+        # a batch that crossed PCIe in bf16 (prefetch.DevicePrefetcher / AudioPortionDataset(wire_dtype='bf16')) is read as it is: the fp32 copy the
+        # kernel used to be handed cost a cast launch and 117 MB of writes + reads per step
+        keep16 = xs.dtype == torch.bfloat16 and dt == torch.bfloat16 and xs2 is None and D % 4 == 0
+        x = xs.contiguous() if keep16 else xs.contiguous().to(torch.float32)
         x2 = xs2.contiguous().to(torch.float32) if xs2 is not None else None
         e = 'model.model.embeddings.'
         st = {'B': B, 'L': Lq, 'N': N, 'lengths': lengths_i32, 'layers': [], 'pack': pack}

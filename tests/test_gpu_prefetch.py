@@ -63,3 +63,26 @@ def test_training_through_the_prefetcher_equals_training_on_resident_batches(kin
         t3 = NativeTrainer(m3, lr=1e-3)
         l3 = [float(t3.step(b)) for b in DevicePrefetcher(iter(src), DEV, depth=2, wire_dtype='bf16')]
         assert l3 == l1 and torch.equal(m1.flat, m3.flat)
+
+
+@pytest.mark.parametrize('packed', [False, True])
+def test_transformer_reads_a_bf16_batch_as_it_is(packed):
+    """A batch that crossed PCIe in bf16 goes into the embedding LayerNorm as bf16 (mts_embed_layernorm_fwd_x16): the same loss, scores and
+    gradients, bit for bit, as the fp32 copy of the same numbers (the fp32 copy is what the step used to make first: a cast launch + 117 MB)."""
+    from multimodaltopicsegmentation_amd import Transformer_segmenter
+    g = torch.Generator().manual_seed(12)
+    B, Lq, D = 5, 40, 256
+    x16 = torch.randn(B, Lq, D, generator=g).to(torch.bfloat16)
+    lengths = torch.tensor([40, 11, 40, 3, 27]) if packed else torch.full((B,), Lq)
+    y = (torch.rand(B, Lq, generator=g) < 0.2).float()
+    for b, n in enumerate(lengths.tolist()):
+        y[b, n:] = -1.0
+    res = []
+    for xin in (x16.to(DEV), x16.to(torch.float32).to(DEV)):
+        m = Transformer_segmenter(2, D, 64, num_layers=1, nheads=4, loss_fn='FocalLoss', window_size=8, compute_dtype='bf16',
+                                  max_position_embedding=128, seed=4).to(DEV)
+        loss, scores = m.loss_and_grad(xin, lengths, y.to(DEV), True)
+        torch.cuda.synchronize()
+        res.append((float(loss), scores.clone(), m.grad_flat().clone()))
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
