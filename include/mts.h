@@ -172,6 +172,20 @@ int mts_layernorm_bwd(void* stream, int dtype, int rows, int D, const void* x, c
                       const float* gamma, const float* mean, const float* rstd,
                       void* dx, float* dgamma, float* dbeta, float* dxsum, void* partial,
                       const float* beta, float* dhead_w, float* dhead_b);
+/* THE LAST LAYER'S TAIL IN ONE PASS (training): LayerNorm forward + tagger head + masked loss + loss gradient + head data gradient + LayerNorm
+ * backward of x = the layer's pre-LayerNorm sum s2 [rows, D], row by row -- what mts_layernorm_fwd(head) + mts_tagger_loss (+ mts_scale) +
+ * mts_layernorm_bwd(head, dhead_w) do in four launches and two reads of x.  (modeling_longformer.py:1127-1131, models/CRF.py:579-595,
+ * focal_loss.py:38-57 and their backward.)  scores fp32 [rows, n_out]; loss_out fp32 [2] = {loss, rows averaged}; dx act dtype [rows, D];
+ * dgamma / dbeta / dxsum (may be NULL) fp32 [D]; dhead_w fp32 [n_out, D], dhead_b [n_out] (all OVERWRITTEN).  Batch description as
+ * mts_tagger_loss (targets fp32 [B, Lt], lengths, packed rows through row_src / n_rows); grad_scale multiplies d loss / d scores.
+ * n_out = 1 (BCE / focal) or 2 (CrossEntropy); D in {256, 512, 1024, 1792, 2048}: mts_layernorm_loss_tail_supported.  Scores and gradients are
+ * bitwise those of the four launches; the loss differs by the grouping of its partial sums.  workspace: mts_layernorm_bwd_workspace(D) bytes. */
+int mts_layernorm_loss_tail_supported(int dtype, int D, int n_out);
+int mts_layernorm_loss_tail(void* stream, int dtype, int rows, int D, const void* x, const float* gamma, const float* beta, float eps,
+                            const float* head_w, const float* head_b, int n_out, int loss_kind, int B, int L, int Lt, const float* targets,
+                            const int32_t* lengths, float alpha, float gamma_focal, float grad_scale, const int32_t* row_src, int n_rows,
+                            float* scores, float* loss_out, void* dx, float* dgamma, float* dbeta, float* dxsum, float* dhead_w,
+                            float* dhead_b, void* workspace);
 /* Backward of the embedding block in ONE pass (modeling_longformer.py:402-426: LN(x + pos[2+i] + type0)): dh (act dtype [rows, D]) is
  * the gradient at the LayerNorm's output, pre / mean / rstd what mts_embed_layernorm_fwd saved.  OVERWRITES dgamma, dbeta, dtype0
  * (= sum over all rows of the pre-LN gradient: the token-type row 0) and rows pos_offset .. pos_offset+L-1 of dpos (= the sum over the

@@ -60,6 +60,9 @@ SIGNATURES = {
     'mts_layernorm_fwd': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'mts_layernorm_bwd_workspace': (_sz, [_i]),
     'mts_layernorm_bwd': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'mts_layernorm_loss_tail_supported': (_i, [_i, _i, _i]),
+    'mts_layernorm_loss_tail': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp,
+                                     _vp, _vp, _vp, _vp]),
     'mts_embed_layernorm_bwd_workspace': (_sz, [_i, _i, _i]),
     'mts_embed_layernorm_bwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz]),
     'mts_embed_bwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),

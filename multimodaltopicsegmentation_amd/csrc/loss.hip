@@ -19,34 +19,7 @@ __device__ __forceinline__ float block_sum_1024(float v, float* red) {
   return red[0];
 }
 
-// models/focal_loss.py:38-57 for one element; returns loss, writes dloss/dx
-__device__ __forceinline__ float focal_elem(float x, float y, float alpha, float gamma, float& grad) {
-  const float p = sigmoid_f(x);
-  // BCE with logits, stable: max(x,0) - x*y + log1p(exp(-|x|))
-  const float ce = fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
-  const float pt = p * y + (1.f - p) * (1.f - y);
-  const float om = 1.f - pt;
-  float mod, dmod;   // (1-pt)^gamma and its derivative wrt pt
-  if (gamma == 2.f) { mod = om * om; dmod = -2.f * om; }
-  else if (gamma == 0.f) { mod = 1.f; dmod = 0.f; }
-  else { mod = powf(om, gamma); dmod = (om > 0.f) ? -gamma * powf(om, gamma - 1.f) : 0.f; }
-  const float at = (alpha >= 0.f) ? alpha * y + (1.f - alpha) * (1.f - y) : 1.f;
-  // d ce/dx = p - y ; d pt/dx = (2y-1) p (1-p)
-  const float dpt = (2.f * y - 1.f) * p * (1.f - p);
-  grad = at * ((p - y) * mod + ce * dmod * dpt);
-  return at * ce * mod;
-}
-
-// nn.BCELoss(sigmoid(x), y) with the log clamp at -100 (models/CRF.py:303, :345-352)
-__device__ __forceinline__ float bce_elem(float x, float y, float& grad) {
-  const float p = sigmoid_f(x);
-  const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.f - p), -100.f);
-  // gradient through the clamps as autograd sees them: d/dp [-y log p] = -y/p unless clamped
-  const float dlp = (logf(p) > -100.f) ? 1.f / p : 0.f;
-  const float dl1p = (logf(1.f - p) > -100.f) ? -1.f / (1.f - p) : 0.f;
-  grad = -(y * dlp + (1.f - y) * dl1p) * p * (1.f - p);
-  return -(y * lp + (1.f - y) * l1p);
-}
+#include "loss_elems.h"
 
 __global__ __launch_bounds__(256) void tagger_loss_kernel(int kind, int B, int L, int Lt, int n_out, const float* __restrict__ scores,
                                                            const float* __restrict__ targets, const int32_t* __restrict__ lengths,

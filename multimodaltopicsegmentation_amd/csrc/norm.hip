@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <type_traits>
 #include "common.h"
+#include "loss_elems.h"
 
 #define ROW_WAVES 4            // waves (= rows in flight) per workgroup
 #define BWD_MAX_BLOCKS 512
@@ -566,6 +567,253 @@ __global__ __launch_bounds__(256) void ln_head_final_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The LAST layer's tail in ONE pass (training): LayerNorm forward + tagger head + masked loss + loss gradient + head data gradient + LayerNorm
+// backward, row by row.  (modeling_longformer.py:1127-1131 -> models/CRF.py:579-595 -> focal_loss.py:38-57, and their backward.)
+// Unfused these are four launches around a 16 384-float tensor: ln_fwd_kernel (reads s2, writes scores), tagger_loss_kernel (+ final), a scale,
+// ln_bwd_kernel<NHG> (reads s2 AGAIN, writes ds2).  Everything between the two reads of a row is a function of that row alone -- the loss
+// normaliser 1 / (number of averaged rows) follows from the lengths (BCE / focal) or the targets (CE) without looking at a score -- so one wave
+// can take a row through all of it while it holds the row in registers: s2 is read once, scores / loss partials / ds2 written once.
+// Arithmetic, in order, is that of the kernels it replaces (row_stats; y = xhat * gamma + beta rounded to the act dtype for the head's dot product,
+// summed per lane over i then j, wave_sum; focal_elem / bce_elem / ce2_elem; g * inv, then * grad_scale; the NHG branch of ln_bwd_kernel):
+// scores and every gradient are bitwise those of the unfused path, the loss differs by the grouping of its partial sums
+// (tests/test_gpu_norm_fused.py::test_last_layer_tail_in_one_pass).  D == NV * 256 only; slabs as the NHG form, finished by ln_head_final_kernel.
+struct TailArgs {
+  int kind, B, L, Lt, n_rows;
+  const float* targets; const int32_t* lengths; const int32_t* row_src;
+  float alpha, gamma_f, grad_scale;
+  float* scores; float* loss_part; float* loss_out;
+};
+
+template <typename T, int NV, int NHG>
+__global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_tail_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                                    const float* __restrict__ head_w, const float* __restrict__ head_b, int rows, int D,
+                                                                    T* __restrict__ dx, float* __restrict__ partial, const TailArgs ta) {
+  constexpr int NS = NHG + 2;
+  __shared__ float red[ROW_WAVES][NHG + 1][64 * 4];
+  __shared__ __attribute__((aligned(16))) float gam_s[NV * 256];
+  __shared__ __attribute__((aligned(16))) float bet_s[NV * 256];
+  __shared__ __attribute__((aligned(16))) float hw_s[NHG][NV * 256];
+  __shared__ float cred[ROW_WAVES];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int idx = threadIdx.x; idx < NV * 256; idx += 64 * ROW_WAVES) {
+    gam_s[idx] = gamma[idx];
+    bet_s[idx] = beta[idx];
+#pragma unroll
+    for (int c = 0; c < NHG; ++c) hw_s[c][idx] = head_w[(size_t)c * D + idx];
+  }
+  // how many rows the loss averages over (tagger_loss_kernel's pass 1): every workgroup counts for itself, in the same order
+  float cnt = 0.f;
+  if (ta.kind == MTS_LOSS_CE) {                   // ignore_index = -1 (CRF.py:298)
+    for (int r = threadIdx.x; r < rows; r += 64 * ROW_WAVES) {
+      const int src = ta.row_src ? ta.row_src[r] : r;
+      cnt += (ta.targets[(size_t)(src / ta.L) * ta.Lt + src % ta.L] != -1.f) ? 1.f : 0.f;
+    }
+  } else {                                        // un-pad loop (CRF.py:348-350): rows i < len_b
+    for (int b = threadIdx.x; b < ta.B; b += 64 * ROW_WAVES) cnt += (float)(ta.lengths ? min(max(ta.lengths[b], 0), ta.L) : ta.L);
+  }
+  cnt = wave_sum(cnt);
+  if (lane == 0) cred[wave] = cnt;
+  __syncthreads();
+  cnt = ((cred[0] + cred[1]) + cred[2]) + cred[3];
+  const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+  float hb[NHG];
+#pragma unroll
+  for (int c = 0; c < NHG; ++c) hb[c] = head_b[c];
+
+  float acc[NHG][NV][4], dxs[NV][4], tsum[NHG];
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      dxs[i][j] = 0.f;
+#pragma unroll
+      for (int c = 0; c < NHG; ++c) acc[c][i][j] = 0.f;
+    }
+#pragma unroll
+  for (int c = 0; c < NHG; ++c) tsum[c] = 0.f;
+  float lacc = 0.f;
+  const float invD = 1.0f / (float)D;
+  const int stride = gridDim.x * ROW_WAVES;
+  Pack<T, 4> px[NV];
+  float y_n = 0.f;
+  int i_n = 0, len_n = 0;
+  auto fetch = [&](int r) {
+    const int src = ta.row_src ? ta.row_src[r] : r;
+    const int b = src / ta.L;
+    i_n = src - b * ta.L;
+    y_n = ta.targets[(size_t)b * ta.Lt + i_n];
+    len_n = ta.lengths ? ta.lengths[b] : ta.L;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) px[i].load(x + (size_t)r * D + 4 * (lane + 64 * i));
+  };
+  int row = blockIdx.x * ROW_WAVES + wave;
+  if (row >= rows) row = -1;
+  if (row >= 0) fetch(row);
+  while (row >= 0) {
+    const float yt = y_n;
+    const int ipos = i_n, len = len_n;
+    float xh[NV][4];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xh[i][j] = px[i].get(j);
+    const int nrow = (row + stride < rows) ? row + stride : -1;
+    if (nrow >= 0) fetch(nrow);
+    // ---- LayerNorm forward + head (ln_fwd_kernel)
+    float mu, rs;
+    row_stats<NV>(xh, D, lane, mu, rs, eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xh[i][j] = (xh[i][j] - mu) * rs;          // xhat from here on (the forward's own first two operations)
+    float hs[NHG];
+#pragma unroll
+    for (int c = 0; c < NHG; ++c) hs[c] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = 4 * (lane + 64 * i);
+      const float4 g4v = *reinterpret_cast<const float4*>(gam_s + e), b4v = *reinterpret_cast<const float4*>(bet_s + e);
+      const float gv[4] = {g4v.x, g4v.y, g4v.z, g4v.w}, bv[4] = {b4v.x, b4v.y, b4v.z, b4v.w};
+      float yv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) yv[j] = xh[i][j] * gv[j] + bv[j];
+#pragma unroll
+      for (int c = 0; c < NHG; ++c) {
+        const float4 w4v = *reinterpret_cast<const float4*>(hw_s[c] + e);
+        const float wv[4] = {w4v.x, w4v.y, w4v.z, w4v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hs[c] += to_f32(from_f32<T>(yv[j])) * wv[j];
+      }
+    }
+    float sc[NHG];
+#pragma unroll
+    for (int c = 0; c < NHG; ++c) sc[c] = wave_sum(hs[c]) + hb[c];
+    asm volatile("" ::: "memory");          // (the row-invariant LDS operands are read again in every phase: kept in registers across the
+                                            // wave reductions they are 56-84 registers the kernel does not have)
+    // ---- loss + its gradient wrt the scores (tagger_loss_kernel; the same value in every lane)
+    float dl[NHG];
+#pragma unroll
+    for (int c = 0; c < NHG; ++c) dl[c] = 0.f;
+    if constexpr (NHG == 2) {
+      if (yt != -1.f) {
+        float g0, g1;
+        lacc += ce2_elem(sc[0], sc[1], (int)yt, g0, g1);
+        dl[0] = g0 * inv;
+        dl[1] = g1 * inv;
+      }
+    } else {
+      if (ipos < len) {
+        float gr;
+        lacc += (ta.kind == MTS_LOSS_FOCAL) ? focal_elem(sc[0], yt, ta.alpha, ta.gamma_f, gr) : bce_elem(sc[0], yt, gr);
+        dl[0] = gr * inv;
+      }
+    }
+    if (ta.grad_scale != 1.0f) {
+#pragma unroll
+      for (int c = 0; c < NHG; ++c) dl[c] *= ta.grad_scale;
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < NHG; ++c) ta.scores[(size_t)row * NHG + c] = sc[c];
+    }
+    // ---- head data gradient + LayerNorm backward (ln_bwd_kernel, NHG branch)
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = 4 * (lane + 64 * i);
+      float dv[4] = {0.f, 0.f, 0.f, 0.f};
+      const float4 g4v = *reinterpret_cast<const float4*>(gam_s + e);
+      const float gv[4] = {g4v.x, g4v.y, g4v.z, g4v.w};
+#pragma unroll
+      for (int c = 0; c < NHG; ++c) {
+        const float4 w4v = *reinterpret_cast<const float4*>(hw_s[c] + e);
+        const float wv[4] = {w4v.x, w4v.y, w4v.z, w4v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dv[j] += dl[c] * wv[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float gyv = dv[j] * gv[j];
+        s1 += gyv;
+        s2 += gyv * xh[i][j];
+#pragma unroll
+        for (int c = 0; c < NHG; ++c) acc[c][i][j] += dl[c] * xh[i][j];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NHG; ++c) tsum[c] += dl[c];
+    s1 = wave_sum(s1) * invD;
+    s2 = wave_sum(s2) * invD;
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = 4 * (lane + 64 * i);
+      // (dv * gamma is formed a second time, from LDS operands, instead of being kept: 28 registers at D = 1792, the same bits)
+      float dv[4] = {0.f, 0.f, 0.f, 0.f};
+      const float4 g4v = *reinterpret_cast<const float4*>(gam_s + e);
+      const float gv[4] = {g4v.x, g4v.y, g4v.z, g4v.w};
+#pragma unroll
+      for (int c = 0; c < NHG; ++c) {
+        const float4 w4v = *reinterpret_cast<const float4*>(hw_s[c] + e);
+        const float wv[4] = {w4v.x, w4v.y, w4v.z, w4v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dv[j] += dl[c] * wv[j];
+      }
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] = rs * (dv[j] * gv[j] - s1 - xh[i][j] * s2);
+        if constexpr (sizeof(T) == 2) o[j] = to_f32(from_f32<T>(o[j]));
+        dxs[i][j] += o[j];
+      }
+      store4<T>(dx + (size_t)row * D + e, o);
+    }
+    row = nrow;
+  }
+  // ---- combine the waves of the workgroup: slabs (as ln_bwd_kernel NHG) and the loss partial
+  float* slab = partial + (size_t)blockIdx.x * NS * D;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int c = 0; c < NHG; ++c) red[wave][c][lane * 4 + j] = acc[c][i][j];
+      red[wave][NHG][lane * 4 + j] = dxs[i][j];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < (NHG + 1) * 256; t += 64 * ROW_WAVES) {
+      const int slot = t / 256, col = t % 256;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < ROW_WAVES; ++w) s += red[w][slot][col];
+      slab[(size_t)slot * D + 256 * i + col] = s;
+    }
+  }
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < NHG; ++c) red[wave][c][0] = tsum[c];
+    red[wave][NHG][0] = lacc;
+  }
+  __syncthreads();
+  if (threadIdx.x <= NHG) {
+    float s = 0.f;
+    for (int w = 0; w < ROW_WAVES; ++w) s += red[w][threadIdx.x][0];
+    if (threadIdx.x < NHG) slab[(size_t)(NHG + 1) * D + threadIdx.x] = s;
+    else { ta.loss_part[blockIdx.x] = s; if (blockIdx.x == 0) ta.loss_out[1] = cnt; }
+  }
+}
+
+__global__ __launch_bounds__(64) void ln_tail_loss_final_kernel(int nblocks, const float* __restrict__ part, float* __restrict__ loss_out) {
+  float s = 0.f;
+  for (int b = threadIdx.x; b < nblocks; b += 64) s += part[b];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) { const float cnt = loss_out[1]; loss_out[0] = cnt > 0.f ? s * (1.f / cnt) : 0.f; }
+}
+
 // Final step of the EMB form: dpos[i][e] = sum_chunks part[chunk][i][e] for every position, in a fixed order, and the column sums
 // of the workgroup's positions -> tpart[blockIdx.y][e] (their sum over y is the token-type row = the pre-LN gradient summed over all
 // rows; slab_reduce_kernel adds them).  Workgroup = 32 columns x 32 row-groups over L / gridDim.y positions.
@@ -950,6 +1198,55 @@ extern "C" int mts_layernorm_bwd(void* stream, int dtype, int rows, int D, const
     return ln_bwd_launch<bf16_t>((hipStream_t)stream, rows, D, x, dy, dlogit, head_w, n_out, gamma, beta, mean, rstd, dx, dgamma, dbeta, dxsum, dhead_w, dhead_b, partial);
   mts_set_error("mts_layernorm_bwd: bad dtype %d", dtype);
   return MTS_ERR_INVALID;
+}
+
+// ---- the last layer's tail in one pass (ln_tail_kernel) ---------------------------------------------------------------------------------
+extern "C" int mts_layernorm_loss_tail_supported(int dtype, int D, int n_out) {
+  return (dtype == MTS_F32 || dtype == MTS_BF16) && (n_out == 1 || n_out == 2) && D % 256 == 0 &&
+         (D == 256 || D == 512 || D == 1024 || D == 1792 || D == 2048);
+}
+
+template <typename T>
+static int ln_tail_launch(hipStream_t st, int rows, int D, const void* x, const float* gamma, const float* beta, float eps, const float* head_w,
+                          const float* head_b, int n_out, void* dx, float* dgamma, float* dbeta, float* dxsum, float* dhead_w, float* dhead_b,
+                          float* ws, const TailArgs& ta0) {
+  const int nv = D / 256;
+  const int blocks = std::min(BWD_MAX_BLOCKS, ceil_div(rows, ROW_WAVES));
+  TailArgs ta = ta0;
+  ta.loss_part = ws + (size_t)BWD_MAX_BLOCKS * 5 * D;               // behind the slabs (at most 4 full-width slots per workgroup)
+  dispatch_nv8(nv, [&](auto nvc) {
+    constexpr int NV = decltype(nvc)::value;
+    if (n_out == 1)
+      hipLaunchKernelGGL((ln_tail_kernel<T, NV, 1>), dim3(blocks), dim3(64 * ROW_WAVES), 0, st, (const T*)x, gamma, beta, eps, head_w, head_b, rows, D, (T*)dx, ws, ta);
+    else
+      hipLaunchKernelGGL((ln_tail_kernel<T, NV, 2>), dim3(blocks), dim3(64 * ROW_WAVES), 0, st, (const T*)x, gamma, beta, eps, head_w, head_b, rows, D, (T*)dx, ws, ta);
+  });
+  const dim3 fgrid(ceil_div(D, 32));
+  if (n_out == 1)
+    hipLaunchKernelGGL(ln_head_final_kernel<1>, fgrid, dim3(256), 0, st, (const float*)ws, blocks, D, head_w, gamma, beta, dgamma, dbeta, dxsum, dhead_w, dhead_b);
+  else
+    hipLaunchKernelGGL(ln_head_final_kernel<2>, fgrid, dim3(256), 0, st, (const float*)ws, blocks, D, head_w, gamma, beta, dgamma, dbeta, dxsum, dhead_w, dhead_b);
+  hipLaunchKernelGGL(ln_tail_loss_final_kernel, dim3(1), dim3(64), 0, st, blocks, (const float*)ta.loss_part, ta.loss_out);
+  MTS_LAUNCH_CHECK("mts_layernorm_loss_tail");
+  return MTS_OK;
+}
+
+extern "C" int mts_layernorm_loss_tail(void* stream, int dtype, int rows, int D, const void* x, const float* gamma, const float* beta, float eps,
+                                       const float* head_w, const float* head_b, int n_out, int loss_kind, int B, int L, int Lt, const float* targets,
+                                       const int32_t* lengths, float alpha, float gamma_focal, float grad_scale, const int32_t* row_src, int n_rows,
+                                       float* scores, float* loss_out, void* dx, float* dgamma, float* dbeta, float* dxsum, float* dhead_w,
+                                       float* dhead_b, void* workspace) {
+  MTS_CHECK_ARG(rows > 0 && D > 0 && x && gamma && beta && head_w && head_b && targets && scores && loss_out && dx && dgamma && dbeta && dhead_w &&
+                dhead_b && workspace, "mts_layernorm_loss_tail: bad arguments");
+  MTS_CHECK_ARG(B > 0 && L > 0 && Lt >= L, "mts_layernorm_loss_tail: bad batch shape");
+  MTS_CHECK_ARG(loss_kind == MTS_LOSS_CE || loss_kind == MTS_LOSS_BCE || loss_kind == MTS_LOSS_FOCAL, "Choose one of CrossEntropy or BinaryCrossEntropy as loss function");
+  MTS_CHECK_ARG((loss_kind == MTS_LOSS_CE) ? n_out == 2 : n_out == 1, "mts_layernorm_loss_tail: n_out=%d does not match the loss kind", n_out);
+  MTS_CHECK_ARG(row_src ? (n_rows == rows && rows <= B * L) : rows == B * L, "mts_layernorm_loss_tail: rows must be B*L, or n_rows of a packed batch");
+  MTS_UNSUPPORTED(mts_layernorm_loss_tail_supported(dtype, D, n_out), "mts_layernorm_loss_tail: D=%d / n_out=%d not covered (see mts_layernorm_loss_tail_supported)", D, n_out);
+  const TailArgs ta = {loss_kind, B, L, Lt, n_rows, targets, lengths, row_src, alpha, gamma_focal, grad_scale, scores, nullptr, loss_out};
+  if (dtype == MTS_F32)
+    return ln_tail_launch<float>((hipStream_t)stream, rows, D, x, gamma, beta, eps, head_w, head_b, n_out, dx, dgamma, dbeta, dxsum, dhead_w, dhead_b, (float*)workspace, ta);
+  return ln_tail_launch<bf16_t>((hipStream_t)stream, rows, D, x, gamma, beta, eps, head_w, head_b, n_out, dx, dgamma, dbeta, dxsum, dhead_w, dhead_b, (float*)workspace, ta);
 }
 
 // ---- backward of the embedding block in one pass: LayerNorm backward + position / token-type gradient ------------------------------

@@ -216,6 +216,23 @@ def layernorm_bwd(x, dy, gamma, mean, rstd, dx, dgamma, dbeta, dxsum=None, dlogi
                                 ptr(beta), ptr(dhead_w), ptr(dhead_b)))
 
 
+def loss_tail_supported(dtype, D, n_out):
+    return dtype in (torch.float32, torch.bfloat16) and bool(lib.mts_layernorm_loss_tail_supported(dtype_code(dtype), D, n_out))
+
+
+def layernorm_loss_tail(kind, x, gamma, beta, eps, head_w, head_b, targets, lengths, alpha, gamma_f, grad_scale, scores, loss_out, dx, dgamma,
+                        dbeta, dxsum, dhead_w, dhead_b, batch_shape, row_src=None):
+    """The last layer's LayerNorm + head + loss + their backward in one pass over x = s2 [rows, D] (see include/mts.h)."""
+    rows, D = x.shape
+    B, Lq = batch_shape
+    ws = _scratch(lib.mts_layernorm_bwd_workspace(D), x.device, 'ln_bwd')
+    with _timed(('ln_tail', rows, D, head_w.shape[0])):
+        check(lib.mts_layernorm_loss_tail(stream_ptr(), dtype_code(x.dtype), rows, D, ptr(x), ptr(gamma), ptr(beta), eps, ptr(head_w), ptr(head_b),
+                                          head_w.shape[0], kind, B, Lq, targets.shape[1], ptr(targets), ptr(lengths), float(alpha), float(gamma_f),
+                                          float(grad_scale), ptr(row_src), row_src.numel() if row_src is not None else 0, ptr(scores),
+                                          ptr(loss_out), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(dxsum), ptr(dhead_w), ptr(dhead_b), ptr(ws)))
+
+
 def embed_layernorm_bwd(pre, dh, gamma, mean, rstd, B, Lq, dgamma, dbeta, dtype0, dpos, pos_offset, row0=None, lengths=None):
     """Embedding block backward in one pass: dgamma / dbeta / dtype0 and rows pos_offset .. pos_offset + Lq - 1 of dpos are
     overwritten; the pre-LayerNorm gradient is never stored."""

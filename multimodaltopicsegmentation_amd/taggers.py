@@ -213,6 +213,9 @@ class _TaggerBase(FlatModule):
     qkv_release = os.environ.get('MTS_DP_QKV_RELEASE', 'block')    # under a data-parallel hook: 'projection' | 'block' (see _band_layer_bwd)
     fuse_ffn = os.environ.get('MTS_FUSE_FFN', '1') != '0'    # one launch per direction for the feed-forward block where mts_ffn_* covers it
                                                               # (bf16, F = 256, d a multiple of 256, no hidden dropout); bitwise the same results
+    fuse_tail = os.environ.get('MTS_FUSE_TAIL', '1') != '0'  # training: the last layer's LayerNorm + head + loss + their backward in one pass over s2 where
+                                                              # mts_layernorm_loss_tail covers it (n_out <= 2, D in {256, 512, 1024, 1792, 2048}); bitwise the
+                                                              # same scores and gradients as the four launches it replaces
     fuse_ffn_min_rows = 12288        # ... and where its 64-row workgroups fill the chip: below ~192 workgroups the 128x128 GEMM pair is
                                      # 1-2 % faster end to end (8192 rows: 0.432 vs 0.438 ms per inference call; 2437 rows: 0.217 vs 0.221)
 
@@ -220,7 +223,7 @@ class _TaggerBase(FlatModule):
         first, last = names[key]
         return self._wspan(flat, first, last, rows, cols)
 
-    def _band_layer_fwd(self, names, tag, h, lengths_i32, B, Lq, N, radius, row0, pdrop, pattn, head=None, store_out=True):
+    def _band_layer_fwd(self, names, tag, h, lengths_i32, B, Lq, N, radius, row0, pdrop, pattn, head=None, store_out=True, skip_ln2=False):
         """post-LN layer: a = LN(dropout(ctx Wo^T + bo) + h), out = LN(dropout(act(a W1^T + b1) W2^T + b2) + a), ctx = band
         attention over q|k|v = h Wqkv^T + b (q scaled by 1/sqrt(hd)).  modeling_longformer.py:482-640,1061-1172 /
         RestrictedTransformerLayer.py:269-310.  head = (w, b, scores): tagger head fused into the last LayerNorm."""
@@ -275,16 +278,20 @@ class _TaggerBase(FlatModule):
             ops.linear_fwd(f, w2, b2, s2, residual=a1)
         # store_out = False (with a fused head): the layer's output is fed to the head and NOT written -- the native training step never
         # reads it again (the LayerNorm backward recomputes it for the head's weight gradient), forward() only wants the scores
-        hout = ws.get(f'hout{tag}', N, D, dt, dev) if (store_out or head is None) else None
-        mean2 = ws.get(f'mean2_{tag}', N, 1, torch.float32, dev)
-        rstd2 = ws.get(f'rstd2_{tag}', N, 1, torch.float32, dev)
-        ops.layernorm_fwd(s2, self._lt(pf, names, 'ln2w', 1, D).view(-1), self._lt(pf, names, 'ln2b', 1, D).view(-1), self.ln_eps,
-                          hout, mean2, rstd2, head_w=head[0] if head else None, head_b=head[1] if head else None,
-                          scores=head[2] if head else None)
+        if skip_ln2:
+            # the caller takes s2 through the last LayerNorm, the head, the loss and their backward in ONE pass (ops.layernorm_loss_tail)
+            hout = mean2 = rstd2 = None
+        else:
+            hout = ws.get(f'hout{tag}', N, D, dt, dev) if (store_out or head is None) else None
+            mean2 = ws.get(f'mean2_{tag}', N, 1, torch.float32, dev)
+            rstd2 = ws.get(f'rstd2_{tag}', N, 1, torch.float32, dev)
+            ops.layernorm_fwd(s2, self._lt(pf, names, 'ln2w', 1, D).view(-1), self._lt(pf, names, 'ln2b', 1, D).view(-1), self.ln_eps,
+                              hout, mean2, rstd2, head_w=head[0] if head else None, head_b=head[1] if head else None,
+                              scores=head[2] if head else None)
         return dict(hin=h, qkv=qkv, ctx=ctx, probs=probs, s1=s1, a1=a1, mean1=mean1, rstd1=rstd1, u=u, f=f, s2=s2, hout=hout,
                     mean2=mean2, rstd2=rstd2, radius=radius, slots=slots, m1=m1, m2=m2, pattn=pattn, aseed=aseed, fused_ffn=fused)
 
-    def _band_layer_bwd(self, names, S, dh, lengths_i32, B, Lq, N, pdrop, row0, wgrad, tail_end, head=None, slot=0, head_grads=None):
+    def _band_layer_bwd(self, names, S, dh, lengths_i32, B, Lq, N, pdrop, row0, wgrad, tail_end, head=None, slot=0, head_grads=None, tail_done=False):
         """Gradients of one layer into grad_flat; returns d(layer input).  dh: gradient wrt the layer output (None when only the
         fused head contributes); head = (dscores, head_w): the tagger head's data gradient is formed inside the LayerNorm backward.
         wgrad(dy, x, gview): the caller's weight-gradient launcher (may run on a side stream).  tail_end: end offset of the span
@@ -298,11 +305,13 @@ class _TaggerBase(FlatModule):
         Gv = lambda key, rows, cols: self._lt(g, names, key, rows, cols)
         ds2 = ws.get('ds2', N, D, dt, dev)
         # head_grads = (dW_head, db_head): the head's parameter gradients come out of this pass too (last layer, dh is None)
-        ops.layernorm_bwd(S['s2'], dh, self._lt(pf, names, 'ln2w', 1, D).view(-1), S['mean2'], S['rstd2'], ds2,
-                          Gv('ln2w', 1, D).view(-1), Gv('ln2b', 1, D).view(-1), dxsum=Gv('b2', 1, D).view(-1),
-                          dlogit=head[0] if head else None, head_w=head[1] if head else None,
-                          beta=self._lt(pf, names, 'ln2b', 1, D).view(-1) if head_grads else None,
-                          dhead_w=head_grads[0] if head_grads else None, dhead_b=head_grads[1] if head_grads else None)
+        # tail_done: ops.layernorm_loss_tail has produced ds2 and the LayerNorm / head parameter gradients already (loss_and_grad)
+        if not tail_done:
+            ops.layernorm_bwd(S['s2'], dh, self._lt(pf, names, 'ln2w', 1, D).view(-1), S['mean2'], S['rstd2'], ds2,
+                              Gv('ln2w', 1, D).view(-1), Gv('ln2b', 1, D).view(-1), dxsum=Gv('b2', 1, D).view(-1),
+                              dlogit=head[0] if head else None, head_w=head[1] if head else None,
+                              beta=self._lt(pf, names, 'ln2b', 1, D).view(-1) if head_grads else None,
+                              dhead_w=head_grads[0] if head_grads else None, dhead_b=head_grads[1] if head_grads else None)
         # FFN down:  s2 = dropout(f W2^T + b2) + a1
         ds2d = ds2
         if pdrop:
@@ -504,7 +513,7 @@ class Transformer_segmenter(_TaggerBase):
                 'ln2b': one(lp + 'output.LayerNorm.bias')}
 
     # ---- native forward / backward ------------------------------------------------------------------
-    def _forward_native(self, xs, lengths_i32, want_grad_state=True, pack=None, need_hidden=True):
+    def _forward_native(self, xs, lengths_i32, want_grad_state=True, pack=None, need_hidden=True, tail=False):
         """pack = {'row_src', 'row0', 'n'} (see _pack_plan): activations hold only the valid sentences.
         need_hidden = False: the last layer's output goes to the fused head only and is not written to memory."""
         xs, xs2, B, Lq, D = self._split_input(xs)
@@ -541,23 +550,23 @@ class Transformer_segmenter(_TaggerBase):
         scores = ws.get('scores', N, self.n_out, torch.float32, dev)
         for li, radius in enumerate(self.radii):
             last = li == len(self.radii) - 1
-            head = (self._w(pf, 'classification.weight'), self._w(pf, 'classification.bias'), scores) if last else None
+            head = (self._w(pf, 'classification.weight'), self._w(pf, 'classification.bias'), scores) if (last and not tail) else None
             S = self._band_layer_fwd(self._layer_names(li), str(li), h, lengths_i32, B, Lq, N, radius, row0, pdrop,
                                      self.dropout_out if self.training else 0.0, head,
                                      # (a head wider than two outputs takes its parameter gradients from the stored output: _backward_native)
-                                     store_out=need_hidden or not last or self.n_out > 2)
+                                     store_out=need_hidden or not last or self.n_out > 2, skip_ln2=last and tail)
             st['layers'].append(S)
             h = S['hout']
         st['scores'] = scores if pack else scores.view(B, Lq, self.n_out)
         st['hidden'] = h
         return st
 
-    def _backward_native(self, st, dscores):
+    def _backward_native(self, st, dscores, tail_done=False):
         """Fill grad_flat from the saved forward state; dscores fp32 [N, n_out]."""
         dt = self.compute_dtype
         B, Lq, N = st['B'], st['L'], st['N']
         D, F, H = self.embedding_dim, self._ffp, self.nheads
-        dev = dscores.device
+        dev = self._flat.device
         ws, lay = self._ws, self._layout
         wf, pf = self._weights(), self._flat
         g = self.grad_flat()
@@ -586,14 +595,15 @@ class Transformer_segmenter(_TaggerBase):
                 main.wait_stream(side)         # the previous layer's weight gradients are done with ds2 / du / ds1 / dqkv
             # the head's parameter gradients: from the last layer's LayerNorm backward (no pass over the stored output, which the
             # training forward does not even write); a head wider than two outputs keeps its own kernel
-            fuse_hg = last and self.n_out <= 2
-            if last and not fuse_hg:
+            fuse_hg = last and self.n_out <= 2 and not tail_done
+            if last and not fuse_hg and not tail_done:
                 ops.head_bwd_params(st['layers'][li]['hout'], dscores, G('classification.weight'), G('classification.bias'))
             tail_end = lay.entries[f'model.model.encoder.layer.{li + 1}.attention.self.query.weight'][0] if li + 1 < nl else g.numel()
             dh = self._band_layer_bwd(self._layer_names(li), st['layers'][li], dh, st['lengths'], B, Lq, N, st['pdrop'],
                                       st['pack']['row0'] if st['pack'] else None, wgrad, tail_end,
-                                      head=(dscores, self._w(pf, 'classification.weight')) if last else None, slot=li & 1,
-                                      head_grads=(G('classification.weight'), G('classification.bias')) if fuse_hg else None)
+                                      head=(dscores, self._w(pf, 'classification.weight')) if (last and not tail_done) else None, slot=li & 1,
+                                      head_grads=(G('classification.weight'), G('classification.bias')) if fuse_hg else None,
+                                      tail_done=tail_done and last)
         e = 'model.model.embeddings.'
         if st['pdrop']:
             ops.dropout_bwd(dh, dh, st['m0'], st['pdrop'])         # through the dropout behind the embedding LayerNorm
@@ -671,9 +681,26 @@ class Transformer_segmenter(_TaggerBase):
         dev = x1.device
         li32 = self._prep_lengths(lengths, B, Lq, dev)
         pack = self._pack_plan(lengths, B, Lq, dev)
-        st = self._forward_native(xs, li32, pack=pack, need_hidden=False)
         tg = tags.to(device=dev, dtype=torch.float32).contiguous()
         loss_out = torch.empty(2, dtype=torch.float32, device=dev)
+        D = self.embedding_dim
+        if (want_grad and self.fuse_tail and self.n_out == (2 if self.loss_kind == L.LOSS_CE else 1) and tg.shape[1] >= Lq
+                and ops.loss_tail_supported(self.compute_dtype, D, self.n_out)):
+            # the last layer's LayerNorm, the head, the loss and their backward in ONE pass over the layer's pre-LayerNorm sum (mts_layernorm_loss_tail)
+            st = self._forward_native(xs, li32, pack=pack, need_hidden=False, tail=True)
+            nm, pf, g, lay = self._layer_names(len(self.radii) - 1), self._flat, self.grad_flat(), self._layout
+            N = st['N']
+            scores = self._ws.get('scores', N, self.n_out, torch.float32, dev)
+            ds2 = self._ws.get('ds2', N, D, self.compute_dtype, dev)
+            ops.layernorm_loss_tail(self.loss_kind, st['layers'][-1]['s2'], self._lt(pf, nm, 'ln2w', 1, D).view(-1), self._lt(pf, nm, 'ln2b', 1, D).view(-1),
+                                    self.ln_eps, self._w(pf, 'classification.weight'), self._w(pf, 'classification.bias'), tg, li32, self.alpha,
+                                    self.gamma, self.loss_grad_scale, scores, loss_out, ds2, self._lt(g, nm, 'ln2w', 1, D).view(-1),
+                                    self._lt(g, nm, 'ln2b', 1, D).view(-1), self._lt(g, nm, 'b2', 1, D).view(-1), lay.view(g, 'classification.weight'),
+                                    lay.view(g, 'classification.bias'), (B, Lq), row_src=pack['row_src'] if pack else None)
+            st['scores'] = scores if pack else scores.view(B, Lq, self.n_out)
+            self._backward_native(st, None, tail_done=True)
+            return loss_out[0], st['scores']
+        st = self._forward_native(xs, li32, pack=pack, need_hidden=False)
         dsc = self._ws.get('dscores', st['N'], self.n_out, torch.float32, dev) if want_grad else None
         ops.tagger_loss(self.loss_kind, st['scores'], tg, li32, self.alpha, self.gamma, loss_out, dsc,
                         row_src=pack['row_src'] if pack else None, batch_shape=(B, Lq))

@@ -107,3 +107,34 @@ def test_head_parameter_gradients_from_the_layernorm_backward(dtype, rows, D, n_
                                 ('dxsum', dxs.view(-1), x64.grad.sum(0), 2e-2 if bf else 2e-5), ('dhead_w', dhw, w64.grad, 2e-5), ('dhead_b', dhb, hb64.grad, 2e-5)):
         d = (got.cpu().double() - ref).abs().max().item()
         assert d <= tol * max(1.0, ref.abs().max().item()), (name, d, ref.abs().max().item())
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
+@pytest.mark.parametrize('D,loss_fn,ragged,scale', [(256, 'FocalLoss', False, 1.0), (256, 'CrossEntropy', True, 1.0), (512, 'BinaryCrossEntropy', True, 0.5),
+                                                   (1792, 'FocalLoss', True, 1.0), (1792, 'CrossEntropy', False, 2.0), (2048, 'FocalLoss', False, 1.0)])
+def test_last_layer_tail_in_one_pass(D, loss_fn, ragged, scale, dtype):
+    """mts_layernorm_loss_tail (the last layer's LayerNorm + head + loss + their backward in ONE pass over s2) against the four launches it replaces,
+    through `Transformer_segmenter.loss_and_grad` with the switch on and off: scores and EVERY gradient bit for bit, the loss to the grouping of its
+    partial sums; padded and packed batches, all three losses, a loss-gradient weight (token-weighted data parallelism)."""
+    from multimodaltopicsegmentation_amd.taggers import Transformer_segmenter
+    g = torch.Generator().manual_seed(D + len(loss_fn))
+    B, Lq = 6, 48
+    x = torch.randn(B, Lq, D, generator=g)
+    lengths = torch.tensor([48, 7, 48, 1, 30, 19]) if ragged else torch.full((B,), Lq)
+    y = (torch.rand(B, Lq, generator=g) < 0.3).float()
+    for b, n in enumerate(lengths.tolist()):
+        y[b, n:] = -1.0
+    res = {}
+    for fuse in (True, False):
+        m = Transformer_segmenter(2, D, 64, num_layers=2, nheads=4 if D < 1024 else 8, loss_fn=loss_fn, window_size=8, compute_dtype=dtype, max_position_embedding=64,
+                                  seed=3).to(DEV)
+        m.fuse_tail = fuse
+        m.loss_grad_scale = scale
+        loss, scores = m.loss_and_grad(x.to(DEV), lengths, y.to(DEV), True)
+        torch.cuda.synchronize()
+        res[fuse] = (float(loss), scores.clone(), m.grad_flat().clone())
+    assert tuple(res[True][1].shape) == tuple(res[False][1].shape)
+    assert torch.equal(res[True][1], res[False][1]), 'scores'
+    assert torch.equal(res[True][2], res[False][2]), 'gradients'
+    assert abs(res[True][0] - res[False][0]) <= 2e-6 * max(1.0, abs(res[False][0])), (res[True][0], res[False][0])
+    assert torch.count_nonzero(res[True][2]) > 0
