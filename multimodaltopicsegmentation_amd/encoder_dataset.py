@@ -172,6 +172,16 @@ class AudioPortionDataset(Dataset):
             item['embeddings2'] = self.embeddings2[index]
         return item
 
+    def __getstate__(self):
+        """a DataLoader worker gets a COPY of the dataset: pointer tables and ring buffers are rebuilt there, never shipped (their addresses
+        belong to this process)"""
+        d = dict(self.__dict__)
+        d['_tab'] = None
+        d['_tgt_cache'] = {}
+        if d.get('_ring') is not None:
+            d['_ring'] = _PinnedRing(d['_ring'].slots)
+        return d
+
     def __getitems__(self, indices):
         """batched fetch (torch's DataLoader calls this when it exists): ring mode -> the indices themselves, for the collater's fast path"""
         if self._ring is None:

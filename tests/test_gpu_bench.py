@@ -60,6 +60,17 @@ def test_default_line_witnesses_the_other_baseline_configurations():
         seq = 512 if 'configs[4]' in k else 256
         assert abs(v['sentences_per_s'] - 64 * seq * 1e3 / v['ms_per_step']) < 1e-6 * v['sentences_per_s']
     assert j['roofline']['kernel'].startswith('gemm_bf16_224')
+    # ... and the PCIe-inclusive legs, the product's own collater among them: documents -> collater -> prefetcher -> step
+    h = j['extra']['h2d']
+    assert {'collater, fp32 on the wire', 'collater, bf16 on the wire', 'pinned, fp32 on the wire', 'pageable, fp32 on the wire', 'pinned, bf16 on the wire'} <= set(h)
+    for k in ('collater, fp32 on the wire', 'collater, bf16 on the wire'):
+        assert h[k]['ms_per_step'] > 0 and h[k]['collater_ms_per_batch'] > 0 and h[k]['collate_threads'] >= 1, k
+
+
+def test_bench_h2d_collater_line():
+    j = _run('--h2d', 'collater', '--h2d-wire', 'bf16', '--steps', '6', '--warmup', '3', '--docs', '8', '--seq', '128', '--no-cpu-baseline', '--no-other-configs')
+    assert j['h2d']['host_memory'].startswith("the collater's pinned ring") and j['h2d']['wire_dtype'].startswith('bf16')
+    assert j['value'] > 0 and 'PCIe-inclusive' in j['config']['workload']
 
 
 def _run_env(env, *flags):
