@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libmts_hip.so')
-SOURCES = ['gemm.hip', 'gemm256.hip', 'gemm224.hip', 'gemm224r.hip', 'gemm224t.hip', 'gemm224p.hip', 'ffn_fused.hip', 'norm.hip', 'band_attn.hip', 'band_attn_mfma.hip', 'loss.hip', 'dropout.hip', 'optim.hip', 'lstm.hip', 'lstm_mfma.hip', 'lstm_pair.hip', 'crf.hip', 'collate.hip']
+SOURCES = ['gemm.hip', 'gemm256.hip', 'gemm224.hip', 'gemm224r.hip', 'gemm224t.hip', 'gemm224p.hip', 'gemm224n.hip', 'ffn_fused.hip', 'norm.hip', 'band_attn.hip', 'band_attn_mfma.hip', 'loss.hip', 'dropout.hip', 'optim.hip', 'lstm.hip', 'lstm_mfma.hip', 'lstm_pair.hip', 'crf.hip', 'collate.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wno-unused-result']
 
 

@@ -706,6 +706,7 @@ static int launch_one(const GemmArgs& a, int splits, hipStream_t st) {
 int mts_launch_gemm224r(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st);   // gemm224r.hip: four-wave NT form, one tile per workgroup (gemm_bf16_224d_kernel)
 int mts_launch_gemm224t(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st);   // gemm224t.hip: four-wave weight-gradient (TN) form
 int mts_launch_gemm224p(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st);   // gemm224p.hip: four-wave persistent forward (NT) form
+int mts_launch_gemm224n(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st);   // gemm224n.hip: four-wave data-gradient (NN) form
 
 // called from mts_gemm (gemm.hip) when N is a multiple of 224 and the 224-wide tiling fills the CUs better
 int mts_launch_gemm224(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st) {
@@ -717,6 +718,12 @@ int mts_launch_gemm224(const GemmArgs& a, int layout, bool c_is_f32, int splits,
     GemmArgs b = a;
     b.variant = 9;
     rc = mts_launch_gemm224r(b, layout, c_is_f32, splits, st);
+    if (rc >= 0) return rc;
+  }
+  // bf16 C, NN (the data gradients): the four-wave kernel with a k-strided B (gemm224n.hip) where it applies (by default: without a residual;
+  // gemm_variant 10: always); gemm_variant 6 keeps the eight-wave kernel
+  if ((a.variant == 0 || a.variant == 10) && !c_is_f32 && layout == MTS_NN && splits == 1) {
+    const int rc = mts_launch_gemm224n(a, layout, c_is_f32, splits, st);
     if (rc >= 0) return rc;
   }
   // fp32 C, TN (the weight gradients): the four-wave unit-pipelined kernel (gemm224t.hip) where it applies; gemm_variant 6 keeps the eight-wave kernel

@@ -190,6 +190,41 @@ def test_gemm_224t_matches_the_eight_wave_kernel_bitwise(ops, M, N, K, splits):
         assert torch.equal(outs[0][i].view(torch.int32), outs[1][i].view(torch.int32)), ('plain', 'accumulate')[i]
 
 
+@pytest.mark.parametrize('M,N,K', [(256, 224, 128), (256, 224, 192), (512, 448, 256), (768, 224, 1088), (512, 1792, 1792), (1024, 1792, 5376)])
+@pytest.mark.parametrize('epi', ['plain', 'residual', 'bias+residual'])
+def test_gemm_224n_matches_the_eight_wave_kernel_bitwise(ops, M, N, K, epi):
+    """Data gradients (NN, bf16 C): the four-wave kernel with a k-strided B (gemm224n.hip; the default without a residual, gemm_variant 10 for every epilogue) against
+    the eight-wave kernel (gemm_variant 6) -- same accumulation order per output element, same epilogue arithmetic: identical bits.  Covers the minimum of two
+    K-tiles, odd K-tile counts, both step shapes' K, and the residual / bias epilogues; B is a column window of a wider matrix (ldb > N)."""
+    from multimodaltopicsegmentation_amd import _lib as L
+    a = _rnd(M, K, seed=81).to(torch.bfloat16).to(DEV)
+    bw = _rnd(K, N + 224, seed=82, scale=0.2).to(torch.bfloat16).to(DEV)
+    b = bw[:, 224:]
+    res = _rnd(M, N, seed=83).to(torch.bfloat16).to(DEV) if 'residual' in epi else None
+    bias = _rnd(N, seed=84).to(DEV) if 'bias' in epi else None
+    outs = {}
+    try:
+        L.check(L.lib.mts_set_option(b'gemm_tile', 224))
+        for variant in (0, 10, 6):            # default (four-wave without a residual) | four-wave for every epilogue | eight-wave
+            L.check(L.lib.mts_set_option(b'gemm_variant', variant))
+            o = torch.full((M, N), float('nan'), dtype=torch.bfloat16, device=DEV)
+            ops.gemm(L.NN, a, b, o, M=M, N=N, K=K, ldb=N + 224, bias=bias, residual=res)
+            outs[variant] = o.clone()
+    finally:
+        L.check(L.lib.mts_set_option(b'gemm_variant', 0))
+        L.check(L.lib.mts_set_option(b'gemm_tile', 0))
+    torch.cuda.synchronize()
+    assert not torch.isnan(outs[0].float()).any()
+    ref = a.double().cpu() @ b.double().cpu()
+    if res is not None:
+        ref = ref + res.double().cpu()
+    if bias is not None:
+        ref = ref + bias.double().cpu()
+    _close(outs[0].float(), ref, 1e-2, 1e-2 * math.sqrt(K) * 0.2 + 2e-2, 'NN four-wave bf16 C')
+    assert torch.equal(outs[0].view(torch.int16), outs[6].view(torch.int16))
+    assert torch.equal(outs[10].view(torch.int16), outs[6].view(torch.int16))
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_gemm_epilogues(ops, dtype):
     M, N, K = 192, 256, 128

@@ -15,24 +15,7 @@ SHAPES = [('NT', 16384, 5376, 1792), ('NT', 16384, 1792, 1792), ('NN', 16384, 17
           ('TN', 5376, 1792, 16384), ('TN', 1792, 1792, 16384), ('NT', 8192, 8192, 8192)]
 
 
-def timeit(fn, warm=100, reps=3, n=50):
-    """steady state under the kernel's OWN load: the chip manages its clock within milliseconds, so a 20-launch measurement inherits the
-    power state the previous kernel left (the same mts kernel read 257 us behind other mts kernels and 272 behind the vendor's in round 4's
-    first collection).  `warm` untimed launches (>= 20 ms), then the median of `reps` x `n` timed ones."""
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(reps):
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        for _ in range(n):
-            fn()
-        e.record()
-        torch.cuda.synchronize()
-        ts.append(s.elapsed_time(e) * 1e3 / n)
-    return sorted(ts)[len(ts) // 2]
-
+from tools.blas_compare_util import timeit  # noqa: E402
 
 for lay, M, N, K in SHAPES:
     g = torch.Generator(device=dev).manual_seed(1)
