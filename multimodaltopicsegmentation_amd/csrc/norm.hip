@@ -504,11 +504,15 @@ __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_bwd_kernel(
 
 // Final step of the NHG form of ln_bwd_kernel: reduces the slabs (S_c, colsum(dx), T_c) over the workgroups in a fixed order and forms
 // dgamma, dbeta, dxsum, dw[c], db[c] (see the kernel's header).  Workgroup = 32 columns x 32 block-groups, as slab_reduce_kernel.
+// The loads of a lane go out eight blocks at a time (the adds keep their order): one dependent L2 round trip per block made this launch 10 us
+// for 11 MB.  loss_part (the one-pass tail, else NULL): the last workgroup's second wave also finishes the loss -- the sum of the workgroups'
+// partials, lane-strided then wave_sum, times 1 / loss_out[1] -- which used to be a launch of its own.
 template <int NHG>
 __global__ __launch_bounds__(256) void ln_head_final_kernel(const float* __restrict__ partial, int nblocks, int D, const float* __restrict__ head_w,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dxsum,
-                                                            float* __restrict__ dhead_w, float* __restrict__ dhead_b) {
+                                                            float* __restrict__ dhead_w, float* __restrict__ dhead_b,
+                                                            const float* __restrict__ loss_part, float* __restrict__ loss_out) {
   constexpr int NS = NHG + 2;
   __shared__ float4 red[NHG + 1][32][8];
   __shared__ float tred[NHG][256];
@@ -519,10 +523,23 @@ __global__ __launch_bounds__(256) void ln_head_final_kernel(const float* __restr
 #pragma unroll
   for (int k = 0; k <= NHG; ++k) s[k] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e < D) {
-    for (int b = grp; b < nblocks; b += 32) {
+    const float* p = partial + e;
+    int b = grp;
+    for (; b + 32 * 7 < nblocks; b += 32 * 8) {
+      float4 v[8][NHG + 1];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int k = 0; k <= NHG; ++k) v[u][k] = *reinterpret_cast<const float4*>(p + (size_t)(b + 32 * u) * bs + (size_t)k * D);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int k = 0; k <= NHG; ++k) { s[k].x += v[u][k].x; s[k].y += v[u][k].y; s[k].z += v[u][k].z; s[k].w += v[u][k].w; }
+    }
+    for (; b < nblocks; b += 32) {
 #pragma unroll
       for (int k = 0; k <= NHG; ++k) {
-        const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)b * bs + (size_t)k * D + e);
+        const float4 v = *reinterpret_cast<const float4*>(p + (size_t)b * bs + (size_t)k * D);
         s[k].x += v.x; s[k].y += v.y; s[k].z += v.z; s[k].w += v.w;
       }
     }
@@ -537,10 +554,21 @@ __global__ __launch_bounds__(256) void ln_head_final_kernel(const float* __restr
     tred[c][threadIdx.x] = t;
   }
   __syncthreads();
-  if (grp == 0 && e < D) {
+  if (loss_part && blockIdx.x == gridDim.x - 1 && (threadIdx.x >> 6) == 1) {
+    float ls = 0.f;
+    for (int b = threadIdx.x & 63; b < nblocks; b += 64) ls += loss_part[b];
+    ls = wave_sum(ls);
+    if ((threadIdx.x & 63) == 0) { const float cnt = loss_out[1]; loss_out[0] = cnt > 0.f ? ls * (1.f / cnt) : 0.f; }
+  }
+  if (threadIdx.x < 64) {                                  // (wave 0 holds the eight lanes of grp 0)
+    // T_c = sum of the 256 per-thread sums: four per lane in index order, then the wave's fixed-order butterfly -- the same value in every lane
     float T[NHG];
 #pragma unroll
-    for (int c = 0; c < NHG; ++c) { float t = 0.f; for (int k = 0; k < 256; ++k) t += tred[c][k]; T[c] = t; }
+    for (int c = 0; c < NHG; ++c) {
+      const float4 q = *reinterpret_cast<const float4*>(&tred[c][4 * threadIdx.x]);
+      T[c] = wave_sum(((q.x + q.y) + q.z) + q.w);
+    }
+    if (grp != 0 || e >= D) return;
     float S[NHG + 1][4];
 #pragma unroll
     for (int k = 0; k <= NHG; ++k) {
@@ -807,13 +835,6 @@ __global__ __launch_bounds__(64 * ROW_WAVES, 2) void ln_tail_kernel(const T* __r
   }
 }
 
-__global__ __launch_bounds__(64) void ln_tail_loss_final_kernel(int nblocks, const float* __restrict__ part, float* __restrict__ loss_out) {
-  float s = 0.f;
-  for (int b = threadIdx.x; b < nblocks; b += 64) s += part[b];
-  s = wave_sum(s);
-  if (threadIdx.x == 0) { const float cnt = loss_out[1]; loss_out[0] = cnt > 0.f ? s * (1.f / cnt) : 0.f; }
-}
-
 // Final step of the EMB form: dpos[i][e] = sum_chunks part[chunk][i][e] for every position, in a fixed order, and the column sums
 // of the workgroup's positions -> tpart[blockIdx.y][e] (their sum over y is the token-type row = the pre-LN gradient summed over all
 // rows; slab_reduce_kernel adds them).  Workgroup = 32 columns x 32 row-groups over L / gridDim.y positions.
@@ -828,7 +849,15 @@ __global__ __launch_bounds__(256) void pos_sum_kernel(const float* __restrict__ 
   if (e < D) {
     for (int i = i0 + grp; i < i1; i += 32) {
       float4 s = *reinterpret_cast<const float4*>(part + (size_t)i * D + e);
-      for (int c = 1; c < nchunks; ++c) {
+      int c = 1;
+      for (; c + 6 < nchunks; c += 7) {                   // seven loads in flight, the adds in chunk order
+        float4 v[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) v[u] = *reinterpret_cast<const float4*>(part + ((size_t)(c + u) * L + i) * D + e);
+#pragma unroll
+        for (int u = 0; u < 7; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+      }
+      for (; c < nchunks; ++c) {
         const float4 v = *reinterpret_cast<const float4*>(part + ((size_t)c * L + i) * D + e);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       }
@@ -1172,10 +1201,10 @@ static int ln_bwd_launch(hipStream_t st, int rows, int D, const void* x, const v
   }
   if (nhg == 1)
     hipLaunchKernelGGL(ln_head_final_kernel<1>, dim3(ceil_div(D, 32)), dim3(256), 0, st, (const float*)partial, blocks, D, head_w, gamma, beta, dgamma,
-                       dbeta, dxsum, dhead_w, dhead_b);
+                       dbeta, dxsum, dhead_w, dhead_b, (const float*)nullptr, (float*)nullptr);
   else if (nhg == 2)
     hipLaunchKernelGGL(ln_head_final_kernel<2>, dim3(ceil_div(D, 32)), dim3(256), 0, st, (const float*)partial, blocks, D, head_w, gamma, beta, dgamma,
-                       dbeta, dxsum, dhead_w, dhead_b);
+                       dbeta, dxsum, dhead_w, dhead_b, (const float*)nullptr, (float*)nullptr);
   else {
     SlabOuts so = {{dgamma, dbeta, dxsum, nullptr, nullptr, nullptr}, -1, 0, nullptr, -1, 0};
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(D, SR_COLS), 3), dim3(256), 0, st, (const float*)partial, blocks, 3, D, so);
@@ -1223,10 +1252,11 @@ static int ln_tail_launch(hipStream_t st, int rows, int D, const void* x, const 
   });
   const dim3 fgrid(ceil_div(D, 32));
   if (n_out == 1)
-    hipLaunchKernelGGL(ln_head_final_kernel<1>, fgrid, dim3(256), 0, st, (const float*)ws, blocks, D, head_w, gamma, beta, dgamma, dbeta, dxsum, dhead_w, dhead_b);
+    hipLaunchKernelGGL(ln_head_final_kernel<1>, fgrid, dim3(256), 0, st, (const float*)ws, blocks, D, head_w, gamma, beta, dgamma, dbeta, dxsum, dhead_w, dhead_b,
+                       (const float*)ta.loss_part, ta.loss_out);
   else
-    hipLaunchKernelGGL(ln_head_final_kernel<2>, fgrid, dim3(256), 0, st, (const float*)ws, blocks, D, head_w, gamma, beta, dgamma, dbeta, dxsum, dhead_w, dhead_b);
-  hipLaunchKernelGGL(ln_tail_loss_final_kernel, dim3(1), dim3(64), 0, st, blocks, (const float*)ta.loss_part, ta.loss_out);
+    hipLaunchKernelGGL(ln_head_final_kernel<2>, fgrid, dim3(256), 0, st, (const float*)ws, blocks, D, head_w, gamma, beta, dgamma, dbeta, dxsum, dhead_w, dhead_b,
+                       (const float*)ta.loss_part, ta.loss_out);
   MTS_LAUNCH_CHECK("mts_layernorm_loss_tail");
   return MTS_OK;
 }
