@@ -450,12 +450,16 @@ class Transformer_segmenter(_TaggerBase):
         pos = torch.randn(self.max_pos, D, generator=gen) * std
         pos[1].zero_()                                     # padding_idx = 1
         add(g, e + 'position_embeddings.weight', (self.max_pos, D), pos)
-        groups.append(g)
+        gpos = g
         g = []
         add(g, e + 'token_type_embeddings.weight', (2, D), torch.randn(2, D, generator=gen) * std)
         add(g, e + 'LayerNorm.weight', (D,), torch.ones(D))
         add(g, e + 'LayerNorm.bias', (D,), torch.zeros(D))
+        # token-type rows and the embedding LayerNorm sit IN FRONT of the position table: everything the embedding block's backward touches --
+        # they and position rows [0, L + 2) -- is then ONE span of the flat gradient, announced (and exchanged between ranks) as one message at the
+        # very end of the backward, where every collective is exposed (two messages cost a one-rank RCCL group 40 us of stream hand-offs per step)
         groups.append(g)
+        groups.append(gpos)
         for li in range(num_layers):
             lp = f'model.model.encoder.layer.{li}.'
             g = []
@@ -635,8 +639,9 @@ class Transformer_segmenter(_TaggerBase):
         if side is not None:
             main.wait_stream(side)             # every weight gradient has landed before the optimizer (or anyone else) looks
         p0 = lay.entries[e + 'position_embeddings.weight'][0]
-        self._grads_ready(p0 + 2 * D_, p0 + (Lq + 2) * D_)
-        self._grads_ready(lay.entries[e + 'token_type_embeddings.weight'][0], lay.entries['model.model.encoder.layer.0.attention.self.query.weight'][0])
+        t0 = lay.entries[e + 'token_type_embeddings.weight'][0]
+        assert t0 < p0, 'flat layout: token-type rows and embedding LayerNorm in front of the position table'
+        self._grads_ready(t0, p0 + (Lq + 2) * D_)      # (position rows 0 and 1 ride along: never touched, gradient 0)
 
     def _drop_seed(self):
         self._drop_calls += 1

@@ -103,7 +103,7 @@ class NativeTrainer:
             off, shape = m._layout.entries[pos]
             D = shape[1]
             end = off + shape[0] * D
-            return [(off + 2 * D, off + (self._last_L + 2) * D), (end, n)] if off == 0 else [(0, n)]
+            return [(0, off + (self._last_L + 2) * D), (end, n)]      # (what sits in front of the table, and its rows a batch of this length touches)
         return [(0, n)]
 
     def _adam_spans(self):

@@ -58,7 +58,10 @@ def _worker(rank, world, port, out_dir):
     tr._last_L = L
     spans = tr._reduce_spans()
     # rows of the position table that no batch of this length can touch are excluded from the exchange
-    assert spans[0][0] == 2 * D and spans[0][1] == (L + 2) * D and spans[1][1] == model.flat.numel()
+    # (the token-type rows and the embedding LayerNorm sit in front of the table: one span with the rows a batch of this length touches)
+    p0 = model._layout.entries['model.model.embeddings.position_embeddings.weight'][0]
+    assert p0 == model._layout.entries['model.model.embeddings.LayerNorm.bias'][0] + D
+    assert spans[0][0] == 0 and spans[0][1] == p0 + (L + 2) * D and spans[1][0] == p0 + model.max_pos * D and spans[1][1] == model.flat.numel()
     tr.allreduce_grads()
     torch.save({k: v.clone() for k, v in views.items()}, os.path.join(out_dir, f'g{rank}.pt'))
     dist.barrier()

@@ -302,8 +302,9 @@ def test_gradient_ready_spans_are_final_disjoint_and_cover_every_gradient(releas
         covered[a:b] += 1
     assert int(covered.max()) == 1
     assert torch.count_nonzero(final.cpu()[covered == 0]) == 0
-    # per layer: tail block + the q | k | v block (one span, or one per projection, the last with the three biases); embeddings: positions + rest
-    assert len(seen) == (4 if release == 'projection' else 2) * 3 + 2
+    # per layer: tail block + the q | k | v block (one span, or one per projection, the last with the three biases); the embedding block: ONE span
+    # (token-type rows, LayerNorm and the position rows a batch of this length touches are adjacent in the flat layout)
+    assert len(seen) == (4 if release == 'projection' else 2) * 3 + 1
     assert torch.count_nonzero(final) > 0.9 * int(covered.sum())
 
 
