@@ -87,6 +87,14 @@ int mts_gemm_last_plan(int* tile, int* splits);
 /* Measurement aid (per host thread; NULL clears it): fn() is called between the GEMM launch and the split-K reduce launch of every bf16 mts_gemm,
  * so that an event bracket can time the GEMM kernel by itself. */
 int mts_gemm_set_mid_hook(void (*fn)(void));
+/* Two weight gradients of ONE shape in one launch (bf16 operands, fp32 results; the fused feed-forward block's dW1 and dW2, whose 8 output tiles each
+ * fill half the chip at best when launched alone):  C1[M, N] (+)= A1[K, M]^T B1[K, N]  and  C2t[N, M] (+)= (A2[K, M]^T B2[K, N])^T -- the second one
+ * is STORED TRANSPOSED (dW2 = ds2^T f is computed as f^T ds2, the shape of dW1).  A1 / A2 share lda, B1 / B2 share ldb.  Split-K slabs + fixed-order
+ * reduces as mts_gemm (bitwise reproducible); workspace >= mts_wgrad_pair_workspace(M, N, K) bytes (0: shape not covered: M % 256, N % 224, K % 64 --
+ * MTS_ERR_UNSUPPORTED, the caller issues two mts_gemm calls instead).  Replaces the backward of modeling_longformer.py:1113-1131 (parameter part). */
+size_t mts_wgrad_pair_workspace(int M, int N, int K);
+int mts_wgrad_pair(void* stream, int M, int N, int K, const void* A1, const void* B1, float* C1, int ldc1, const void* A2, const void* B2,
+                   float* C2t, int ldc2t, int lda, int ldb, int accumulate, void* workspace, size_t workspace_bytes);
 /* The planner by itself (pure host code, no device call): the tile width and K split mts_gemm WOULD use for this call under the
  * calling thread's options; workspace_bytes = 0 means "no split-K workspace".  tile / splits may be NULL. */
 int mts_gemm_plan(int a_dtype, int c_dtype, int layout, int M, int N, int K, unsigned epilogue, size_t workspace_bytes,

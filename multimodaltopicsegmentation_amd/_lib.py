@@ -50,6 +50,8 @@ SIGNATURES = {
     'mts_gemm_plan': (_i, [_i, _i, _i, _i, _i, _i, _u, _sz, _vp, _vp]),
     'mts_async_status': (_i, []),
     'mts_gemm': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _u, _f, _i, _vp, _sz]),
+    'mts_wgrad_pair_workspace': (_sz, [_i, _i, _i]),
+    'mts_wgrad_pair': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz]),
     'mts_colsum_workspace': (_sz, [_i]),
     'mts_colsum': (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     'mts_cast': (_i, [_vp, _i, _vp, _vp, _sz]),

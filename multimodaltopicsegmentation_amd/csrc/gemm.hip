@@ -593,6 +593,43 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   store4<float>(C + (size_t)m * ldc + n, s);
 }
 
+// Ct[n][m] (+)= sum_z slab[z][m][n]: the same fixed-order sum, stored TRANSPOSED (32 x 32 tiles through LDS) -- the second problem of
+// mts_wgrad_pair is computed as the transpose of the gradient it belongs to
+__global__ __launch_bounds__(256) void splitk_reduce_t_kernel(const float* __restrict__ slab, int splits, int M, int N, float* __restrict__ Ct,
+                                                              int ldc, int accumulate) {
+  __shared__ float tile[32][33];
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const size_t plane = (size_t)M * N;
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int m = m0 + r, n = n0 + tx;
+    float s = 0.f;
+    if (m < M && n < N) {
+      const float* p = slab + (size_t)m * N + n;
+      int z = 0;
+      for (; z + 7 < splits; z += 8) {                  // eight loads in flight, the adds in slice order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(z + u) * plane];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; z < splits; ++z) s += p[(size_t)z * plane];
+    }
+    tile[r][tx] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int n = n0 + r, m = m0 + tx;
+    if (n < N && m < M) {
+      float* o = Ct + (size_t)n * ldc + m;
+      *o = accumulate ? *o + tile[tx][r] : tile[tx][r];
+    }
+  }
+}
+
 template <typename T> __global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, size_t n) {
   size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
@@ -808,6 +845,56 @@ static void plan_bf16(int c_dtype, int layout, int M, int N, int K, unsigned epi
   }
   *use256_out = use256;
   *splits_out = splits;
+}
+
+// ---- two weight gradients of one shape in one launch ------------------------------------------------------------------------------------
+int mts_launch_gemm224t_pair(const GemmArgs& a, int splits, const void* A2, const void* B2, float* slab2, hipStream_t st);   // gemm224t.hip
+bool mts_gemm224t_applies(const GemmArgs& a, int layout, bool c_is_f32, int splits);
+
+static int wgrad_pair_splits(int M, int N, int K, size_t workspace_bytes) {
+  // one round of workgroups: 2 problems x tiles x slices ~ the CUs (slices of at least 128 k, multiples of 64; 32 at most); -1: not covered
+  if (M % 256 || N % 224 || K % 64 || K < 256) return -1;
+  static int cus = 0;
+  if (!cus) { int dev = 0; hipDeviceProp_t pr; cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+  const int nt = (M / 256) * (N / 224);
+  int sp = std::max(1, std::min(32, cus / (2 * nt)));
+  for (; sp >= 1; --sp) {
+    const int ks = ceil_div(ceil_div(K, sp), BK) * BK;
+    if (ceil_div(K, ks) != sp) continue;
+    if (ks >= 128 && K - (sp - 1) * ks >= 128 && (size_t)2 * sp * M * N * sizeof(float) <= workspace_bytes) return sp;
+  }
+  return -1;
+}
+extern "C" size_t mts_wgrad_pair_workspace(int M, int N, int K) {
+  const int sp = wgrad_pair_splits(M, N, K, (size_t)-1);
+  return sp < 1 ? 0 : (size_t)2 * sp * M * N * sizeof(float);
+}
+extern "C" int mts_wgrad_pair(void* stream, int M, int N, int K, const void* A1, const void* B1, float* C1, int ldc1, const void* A2, const void* B2,
+                              float* C2t, int ldc2t, int lda, int ldb, int accumulate, void* workspace, size_t workspace_bytes) {
+  MTS_CHECK_ARG(M > 0 && N > 0 && K > 0 && A1 && B1 && C1 && A2 && B2 && C2t && workspace, "mts_wgrad_pair: bad arguments");
+  MTS_CHECK_ARG(ldc1 >= N && ldc2t >= M && ldc1 % 4 == 0, "mts_wgrad_pair: bad output strides");
+  const int sp = wgrad_pair_splits(M, N, K, workspace_bytes);
+  MTS_UNSUPPORTED(sp >= 1, "mts_wgrad_pair: M=%d N=%d K=%d not covered (M %% 256, N %% 224, K %% 64) or workspace too small", M, N, K);
+  hipStream_t st = (hipStream_t)stream;
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = A1; a.B = B1; a.C = C1;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc1;
+  a.epi = 0; a.colscale = 1.0f;
+  a.ksplit = ceil_div(ceil_div(K, sp), BK) * BK;
+  a.order = 1; a.nbuf = 2; a.variant = 0;
+  float* const planes = (float*)workspace;
+  a.slab = planes;
+  float* const planes2 = planes + (size_t)sp * M * N;
+  MTS_UNSUPPORTED(mts_gemm224t_applies(a, MTS_TN, true, sp), "mts_wgrad_pair: operands not covered by the four-wave weight-gradient kernel (alignment / strides)");
+  const int rc = mts_launch_gemm224t_pair(a, sp, A2, B2, planes2, st);
+  MTS_UNSUPPORTED(rc == MTS_OK, "mts_wgrad_pair: launch refused");
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((size_t)M * (N / 4) + 255) / 256)), dim3(256), 0, st, (const float*)planes, sp, M, N, C1, ldc1,
+                     accumulate ? 1 : 0);
+  hipLaunchKernelGGL(splitk_reduce_t_kernel, dim3(ceil_div(N, 32), ceil_div(M, 32)), dim3(256), 0, st, (const float*)planes2, sp, M, N, C2t, ldc2t,
+                     accumulate ? 1 : 0);
+  MTS_LAUNCH_CHECK("mts_wgrad_pair");
+  return MTS_OK;
 }
 
 extern "C" int mts_gemm_plan(int a_dtype, int c_dtype, int layout, int M, int N, int K, unsigned epilogue, size_t workspace_bytes,

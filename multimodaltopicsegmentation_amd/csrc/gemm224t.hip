@@ -81,7 +81,10 @@ __device__ __forceinline__ void t_block(f32x4 (&acc)[8][7], TFrag (&fa)[2][8], T
 #undef T_SB
 }
 
-__global__ __launch_bounds__(256, 1) void gemm_bf16_224t_kernel(const GemmArgs a, const int splits) {
+// A2 != NULL: a PAIR of problems of one shape in one launch (the two weight gradients of the fused feed-forward block, 8 tiles each: alone a launch
+// fills half the chip at 16 slices): workgroups [0, nt * splits) take (a.A, a.B) -> a.slab, the next nt * splits take (A2, B2) -> slab2.
+__global__ __launch_bounds__(256, 1) void gemm_bf16_224t_kernel(const GemmArgs a, const int splits, const void* __restrict__ A2, const void* __restrict__ B2,
+                                                                float* __restrict__ slab2) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -93,10 +96,13 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_224t_kernel(const GemmArgs a
   // slice after the other, inside a slice bands of four tile rows, column-major inside a band -- the 32 workgroups an XCD runs at a time
   // share 4 A panels and up to 8 B panels of ONE k range.
   int bm0, bn0, z;
+  bool second;
   {
-    const int t = blockIdx.x;
-    const int qq = ntot >> 3, rr = ntot & 7, xcd = t & 7, idx = t >> 3;
-    const int id = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    const int t = blockIdx.x, ngrid = gridDim.x;
+    const int qq = ngrid >> 3, rr = ngrid & 7, xcd = t & 7, idx = t >> 3;
+    int id = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    second = id >= ntot;                                // (only in a pair launch: gridDim.x = 2 ntot)
+    if (second) id -= ntot;
     z = id / nt;
     const int tl = id - z * nt;
     const int band = tl / (4 * ntn), within = tl - band * 4 * ntn;
@@ -107,8 +113,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_224t_kernel(const GemmArgs a
   const int kbeg = z * a.ksplit;
   const int kend = min(a.K, kbeg + a.ksplit);
   const int nu = (kend - kbeg) >> 5;                   // units of 32 k (launcher: >= 4 in every slice)
-  const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(a.A);
-  const bf16_t* __restrict__ B = reinterpret_cast<const bf16_t*>(a.B);
+  const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(second ? A2 : a.A);
+  const bf16_t* __restrict__ B = reinterpret_cast<const bf16_t*>(second ? B2 : a.B);
 
   // ---- copies.  A piece = 4 k-rows x 256 B of one half image, lane-contiguous in the LDS (16 B per lane): lane (lr = lane >> 4, c16 = lane & 15)
   // fills k-row lr, 32-B slot c16 >> 1, half c16 & 1; slot s of k-row r holds source column block s ^ key(r), key(r) = (r & 3) | (((r >> 3) & 1) << 2)
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_224t_kernel(const GemmArgs a
 
   // ---- epilogue: fp32 tile -> C, or -> this slice's plane of the slab ------------------------------------------------------------------
   const int m0 = bm0 + wm * 128, n0 = bn0 + wn * T_HN;
-  float* __restrict__ Cb = a.slab ? a.slab + (size_t)z * a.M * a.N : reinterpret_cast<float*>(a.C);
+  float* __restrict__ Cb = a.slab ? (second ? slab2 : a.slab) + (size_t)z * a.M * a.N : reinterpret_cast<float*>(a.C);
   const size_t ldo = a.slab ? (size_t)a.N : (size_t)a.ldc;
   const bool accum = !a.slab && (a.epi & MTS_EPI_ACCUM);
 #pragma unroll
@@ -287,6 +293,21 @@ int mts_launch_gemm224t(const GemmArgs& a, int layout, bool c_is_f32, int splits
     hipError_t e = hipMemsetAsync(a.chain, 0, ((size_t)nt * sizeof(unsigned) + 15) & ~(size_t)15, st);
     if (e != hipSuccess) { mts_set_error("gemm224t: hipMemsetAsync: %s", hipGetErrorString(e)); return MTS_ERR_LAUNCH; }
   }
-  hipLaunchKernelGGL(k, dim3(nt * splits), dim3(256), T_LDS, st, a, splits);
+  hipLaunchKernelGGL(k, dim3(nt * splits), dim3(256), T_LDS, st, a, splits, (const void*)nullptr, (const void*)nullptr, (float*)nullptr);
+  return MTS_OK;
+}
+
+// two problems of one shape, both into slabs (a.slab / slab2, `splits` planes each; a.chain must be NULL): see the kernel's header
+int mts_launch_gemm224t_pair(const GemmArgs& a, int splits, const void* A2, const void* B2, float* slab2, hipStream_t st) {
+  if (!mts_gemm224t_applies(a, MTS_TN, true, splits) || !a.slab || a.chain || !A2 || !B2 || !slab2 || (((uintptr_t)A2 | (uintptr_t)B2) & 15)) return -1;
+  auto k = gemm_bf16_224t_kernel;
+  static std::atomic<bool> attr_set{false};
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+    if (e != hipSuccess) { mts_set_error("gemm224t: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MTS_ERR_LAUNCH; }
+    attr_set = true;
+  }
+  const int nt = (a.M / 256) * (a.N / T_BN);
+  hipLaunchKernelGGL(k, dim3(2 * nt * splits), dim3(256), T_LDS, st, a, splits, A2, B2, slab2);
   return MTS_OK;
 }

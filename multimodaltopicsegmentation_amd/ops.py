@@ -161,6 +161,24 @@ def linear_wgrad(dy, x, out, **kw):
     return gemm(L.TN, dy, x, out, M=dy.shape[1], N=x.shape[1], K=dy.shape[0], **kw)
 
 
+def wgrad_pair_supported(dy1, x1):
+    """Can the two weight gradients dy1^T x1 and (their twin of the same shape) go out as one launch?  (include/mts.h mts_wgrad_pair)"""
+    return dy1.dtype == torch.bfloat16 and dy1.is_cuda and lib.mts_wgrad_pair_workspace(dy1.shape[1], x1.shape[1], dy1.shape[0]) > 0
+
+
+def wgrad_pair(dy1, x1, out1, dy2, x2, out2_t, accumulate=False):
+    """out1[M, N] (fp32) = dy1[K, M]^T x1[K, N]  and  out2_t[N, M] = (dy2[K, M]^T x2[K, N])^T  in ONE launch + two fixed-order reduces."""
+    K, M = dy1.shape
+    N = x1.shape[1]
+    assert dy2.shape == dy1.shape and x2.shape == x1.shape and dy2.stride(0) == dy1.stride(0) and x2.stride(0) == x1.stride(0)
+    assert tuple(out1.shape) == (M, N) and out2_t.shape[0] == N and out2_t.shape[1] >= M
+    nbytes = lib.mts_wgrad_pair_workspace(M, N, K)
+    ws = _scratch(nbytes, dy1.device, 'wgrad_pair')
+    with _timed(('wgrad_pair', M, N, K)):
+        check(lib.mts_wgrad_pair(stream_ptr(), M, N, K, ptr(dy1), ptr(x1), ptr(out1), out1.stride(0), ptr(dy2), ptr(x2), ptr(out2_t), out2_t.stride(0),
+                                 dy1.stride(0), x1.stride(0), 1 if accumulate else 0, ptr(ws), nbytes))
+
+
 def colsum(x, out, accumulate=False):
     M, N = x.shape
     ws = _scratch(lib.mts_colsum_workspace(N), x.device, 'colsum')

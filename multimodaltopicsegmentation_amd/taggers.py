@@ -291,7 +291,10 @@ class _TaggerBase(FlatModule):
         return dict(hin=h, qkv=qkv, ctx=ctx, probs=probs, s1=s1, a1=a1, mean1=mean1, rstd1=rstd1, u=u, f=f, s2=s2, hout=hout,
                     mean2=mean2, rstd2=rstd2, radius=radius, slots=slots, m1=m1, m2=m2, pattn=pattn, aseed=aseed, fused_ffn=fused)
 
-    def _band_layer_bwd(self, names, S, dh, lengths_i32, B, Lq, N, pdrop, row0, wgrad, tail_end, head=None, slot=0, head_grads=None, tail_done=False):
+    pair_ffn_wgrads = os.environ.get('MTS_PAIR_FFN_WGRADS', '1') == '1'
+
+    def _band_layer_bwd(self, names, S, dh, lengths_i32, B, Lq, N, pdrop, row0, wgrad, tail_end, head=None, slot=0, head_grads=None, tail_done=False,
+                        wgrad_direct=True):
         """Gradients of one layer into grad_flat; returns d(layer input).  dh: gradient wrt the layer output (None when only the
         fused head contributes); head = (dscores, head_w): the tagger head's data gradient is formed inside the LayerNorm backward.
         wgrad(dy, x, gview): the caller's weight-gradient launcher (may run on a side stream).  tail_end: end offset of the span
@@ -324,9 +327,15 @@ class _TaggerBase(FlatModule):
         if S.get('fused_ffn') and not pdrop:
             # du = (ds2 W2) * act'(u) and da1 = du W1 + ds2 in one launch (the intermediate stays in LDS); weight gradients as before
             ops.ffn_bwd_data(ds2, self._lt(wf, names, 'w1', F, D), self._lt(wf, names, 'w2', D, F), S['u'], du, da1, relu=self.ffn_act == 'relu')
-            wgrad(ds2, S['f'], Gv('w2', D, F))
-            ops.colsum(du, Gv('b1', 1, F).view(-1))
-            wgrad(du, S['a1'], Gv('w1', F, D))
+            if self.pair_ffn_wgrads and wgrad_direct and ops.wgrad_pair_supported(du, S['a1']):
+                # dW1 = du^T a1 and dW2 = ds2^T f (computed as f^T ds2, stored transposed) are two problems of ONE shape, 8 output tiles each:
+                # one launch fills the chip, two fill half of it twice (63 -> ~40 us per step at the BASELINE shape)
+                ops.colsum(du, Gv('b1', 1, F).view(-1))
+                ops.wgrad_pair(du, S['a1'], Gv('w1', F, D), S['f'], ds2, Gv('w2', D, F))
+            else:
+                wgrad(ds2, S['f'], Gv('w2', D, F))
+                ops.colsum(du, Gv('b1', 1, F).view(-1))
+                wgrad(du, S['a1'], Gv('w1', F, D))
         else:
             wgrad(ds2d, S['f'], Gv('w2', D, F))
             ops.linear_dgrad(ds2d, self._lt(wf, names, 'w2', D, F), du)
@@ -607,7 +616,7 @@ class Transformer_segmenter(_TaggerBase):
                                       st['pack']['row0'] if st['pack'] else None, wgrad, tail_end,
                                       head=(dscores, self._w(pf, 'classification.weight')) if (last and not tail_done) else None, slot=li & 1,
                                       head_grads=(G('classification.weight'), G('classification.bias')) if fuse_hg else None,
-                                      tail_done=tail_done and last)
+                                      tail_done=tail_done and last, wgrad_direct=side is None)
         e = 'model.model.embeddings.'
         if st['pdrop']:
             ops.dropout_bwd(dh, dh, st['m0'], st['pdrop'])         # through the dropout behind the embedding LayerNorm

@@ -225,6 +225,47 @@ def test_gemm_224n_matches_the_eight_wave_kernel_bitwise(ops, M, N, K, epi):
     assert torch.equal(outs[10].view(torch.int16), outs[6].view(torch.int16))
 
 
+@pytest.mark.parametrize('M,N,K', [(256, 224, 256), (256, 224, 1088), (512, 448, 4096), (256, 1792, 16384), (256, 1792, 6000 // 64 * 64)])
+def test_wgrad_pair_matches_two_launches(ops, M, N, K):
+    """mts_wgrad_pair (the fused feed-forward block's two weight gradients as ONE launch of the four-wave weight-gradient kernel + two fixed-order
+    reduces, the second result stored transposed) against the two mts_gemm calls it replaces and against fp64: same products, another grouping of
+    the K slices -> equal to fp32 summation noise; bitwise reproducible from call to call; plain and accumulating stores; padded output rows."""
+    from multimodaltopicsegmentation_amd import _lib as L
+    a1 = _rnd(K, M, seed=91).to(torch.bfloat16).to(DEV)
+    b1 = _rnd(K, N, seed=92).to(torch.bfloat16).to(DEV)
+    a2 = _rnd(K, M, seed=93).to(torch.bfloat16).to(DEV)
+    b2 = _rnd(K, N, seed=94).to(torch.bfloat16).to(DEV)
+    assert ops.wgrad_pair_supported(a1, b1)
+    base1, base2 = _rnd(M, N, seed=95).to(DEV), _rnd(N, M + 8, seed=96).to(DEV)
+    outs = []
+    for rep in range(2):
+        o1 = torch.full((M, N), float('nan'), device=DEV)
+        o2 = torch.full((N, M + 8), float('nan'), device=DEV)          # the transposed result lands in a wider buffer (padded storage)
+        ops.wgrad_pair(a1, b1, o1, a2, b2, o2)
+        acc1, acc2 = base1.clone(), base2.clone()
+        ops.wgrad_pair(a1, b1, acc1, a2, b2, acc2, accumulate=True)
+        outs.append((o1.clone(), o2.clone(), acc1.clone(), acc2.clone()))
+    torch.cuda.synchronize()
+    for x, y in zip(outs[0], outs[1]):
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+    o1, o2, acc1, acc2 = outs[0]
+    assert torch.isnan(o2[:, M:]).all() and not torch.isnan(o2[:, :M]).any() and not torch.isnan(o1).any()
+    r1 = a1.double().t().cpu() @ b1.double().cpu()
+    r2 = (a2.double().t().cpu() @ b2.double().cpu()).t()
+    _close(o1, r1, 1e-4, 1e-4 * math.sqrt(K), 'pair problem 1')
+    _close(o2[:, :M], r2, 1e-4, 1e-4 * math.sqrt(K), 'pair problem 2 (transposed)')
+    _close(acc1, r1 + base1.double().cpu(), 1e-4, 1e-4 * math.sqrt(K), 'pair problem 1, accumulate')
+    _close(acc2[:, :M], r2 + base2[:, :M].double().cpu(), 1e-4, 1e-4 * math.sqrt(K), 'pair problem 2, accumulate')
+    assert torch.equal(acc2[:, M:], base2[:, M:])
+    # the two-launch path
+    g1 = torch.empty(M, N, device=DEV)
+    g2 = torch.empty(N, M, device=DEV)
+    ops.gemm(L.TN, a1, b1, g1, M=M, N=N, K=K)
+    ops.gemm(L.TN, b2, a2, g2, M=N, N=M, K=K)
+    _close(o1, g1.double().cpu(), 1e-5, 2e-5 * math.sqrt(K), 'pair vs mts_gemm, problem 1')
+    _close(o2[:, :M], g2.double().cpu(), 1e-5, 2e-5 * math.sqrt(K), 'pair vs mts_gemm, problem 2')
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_gemm_epilogues(ops, dtype):
     M, N, K = 192, 256, 128

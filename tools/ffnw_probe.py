@@ -1,0 +1,19 @@
+import os, sys, torch
+sys.path.insert(0, '/root/repo')
+from multimodaltopicsegmentation_amd import _lib as L, ops
+from tools.blas_compare_util import timeit
+dev='cuda'
+g=torch.Generator(device=dev).manual_seed(1)
+K=16384
+for (M,N) in [(256,1792),(1792,256)]:
+    A=torch.randn(K,M,device=dev,generator=g).to(torch.bfloat16)
+    B=torch.randn(K,N,device=dev,generator=g).to(torch.bfloat16)
+    out=torch.empty(M,N,device=dev)
+    for tile,sp in [(0,0),(224,8),(224,16),(224,12),(128,16),(128,8)]:
+        if tile==224 and N%224: continue
+        L.check(L.lib.mts_set_option(b'gemm_tile',tile)); L.check(L.lib.mts_set_option(b'gemm_splits',sp))
+        try:
+            t=timeit(lambda: ops.gemm(L.TN,A,B,out,M=M,N=N,K=K))
+        finally:
+            L.check(L.lib.mts_set_option(b'gemm_tile',0)); L.check(L.lib.mts_set_option(b'gemm_splits',0))
+        print(f'TN M={M} N={N} K={K} tile={tile} splits={sp}: {t:.1f} us (GEMM + reduce)', flush=True)
