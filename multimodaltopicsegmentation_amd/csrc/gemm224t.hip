@@ -83,6 +83,8 @@ __device__ __forceinline__ void t_block(f32x4 (&acc)[8][7], TFrag (&fa)[2][8], T
 
 // A2 != NULL: a PAIR of problems of one shape in one launch (the two weight gradients of the fused feed-forward block, 8 tiles each: alone a launch
 // fills half the chip at 16 slices): workgroups [0, nt * splits) take (a.A, a.B) -> a.slab, the next nt * splits take (A2, B2) -> slab2.
+// (PAIR is a template parameter so that the pair launch is a symbol of its own in a kernel trace: per-symbol averages stay per call site)
+template <bool PAIR>
 __global__ __launch_bounds__(256, 1) void gemm_bf16_224t_kernel(const GemmArgs a, const int splits, const void* __restrict__ A2, const void* __restrict__ B2,
                                                                 float* __restrict__ slab2) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_224t_kernel(const GemmArgs a
     const int t = blockIdx.x, ngrid = gridDim.x;
     const int qq = ngrid >> 3, rr = ngrid & 7, xcd = t & 7, idx = t >> 3;
     int id = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
-    second = id >= ntot;                                // (only in a pair launch: gridDim.x = 2 ntot)
+    second = PAIR && id >= ntot;                        // (pair launch: gridDim.x = 2 ntot)
     if (second) id -= ntot;
     z = id / nt;
     const int tl = id - z * nt;
@@ -281,7 +283,7 @@ bool mts_gemm224t_applies(const GemmArgs& a, int layout, bool c_is_f32, int spli
 // called from mts_launch_gemm224 (gemm224.hip); -1: shape not covered here
 int mts_launch_gemm224t(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st) {
   if (!mts_gemm224t_applies(a, layout, c_is_f32, splits)) return -1;
-  auto k = gemm_bf16_224t_kernel;
+  auto k = gemm_bf16_224t_kernel<false>;
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
@@ -300,7 +302,7 @@ int mts_launch_gemm224t(const GemmArgs& a, int layout, bool c_is_f32, int splits
 // two problems of one shape, both into slabs (a.slab / slab2, `splits` planes each; a.chain must be NULL): see the kernel's header
 int mts_launch_gemm224t_pair(const GemmArgs& a, int splits, const void* A2, const void* B2, float* slab2, hipStream_t st) {
   if (!mts_gemm224t_applies(a, MTS_TN, true, splits) || !a.slab || a.chain || !A2 || !B2 || !slab2 || (((uintptr_t)A2 | (uintptr_t)B2) & 15)) return -1;
-  auto k = gemm_bf16_224t_kernel;
+  auto k = gemm_bf16_224t_kernel<true>;
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
