@@ -448,7 +448,7 @@ def main():
     dom_key = max(wsym.items(), key=lambda kv: kv[1])[0] if wsym else None
     # (fewer than two warm-up steps: nothing was measured yet, so bracket everything as before)
     timer = None if args.no_kernel_timer else ops.KernelTimer(
-        only=(lambda tag: (tag[0] == 'gemm' and (tag[1], tag[7]) == dom_key) or tag[0] == 'band_fwd') if dom_key is not None else None)
+        only=(lambda tag: tag[0] == 'gemm' and (tag[1], tag[7]) == dom_key) if dom_key is not None else None)
     # ... and only in every `--timer-every`-th step of the region (default 5): measured on MI355X, three bracketed launches per step cost
     # 0.08-0.16 ms of a 1.95 ms step (each event is a timestamp packet behind a queue barrier) -- 2.05 ms with every step bracketed against
     # 1.95 ms with none, same build, same box.  `launches_timed` in the JSON says how many launches the average is over.
@@ -557,10 +557,12 @@ def main():
                                'algorithmic_gflop_per_launch': dom['flop'] / dom['launches'] / 1e9}
             if traffic_note:
                 out['roofline']['traffic_note'] = traffic_note
-            out['kernels_note'] = 'per-launch averages from the warm-up steps (every GEMM / band launch bracketed by HIP events; the bracket of a split-K weight gradient ends before its reduce launch: mts_gemm_set_mid_hook); the roofline entry and band_attn_fwd are from the timed region'
+            out['kernels_note'] = 'per-launch averages from the warm-up steps (every GEMM / band launch bracketed by HIP events; the bracket of a split-K weight gradient ends before its reduce launch: mts_gemm_set_mid_hook); the roofline entry is from the timed region'
             out['kernels'] = {sym.get(k, str(k)): {'launches': d['launches'], 'avg_us': 1e3 * d['ms'] / d['launches'],
                                                     'tflops': d['flop'] / (d['ms'] * 1e-3) / 1e12} for k, d in wper_sym.items()}
             # the HBM-bound headline kernel: band attention, 14 336 algorithmic bytes per sentence (bf16 q,k,v in, ctx out)
+            if 'band_fwd' not in other and 'band_fwd' in wother:
+                other['band_fwd'] = wother['band_fwd']          # (bracketed in the warm-up steps only: every bracket in the timed region costs the step ~16 us)
             if 'band_fwd' in other:
                 by = int(batch['src_lengths'].sum()) * 4 * D * (2 if args.dtype == 'bf16' else 4)
                 gbs = by / (other['band_fwd']['avg_us'] * 1e-6) / 1e9
