@@ -1011,7 +1011,7 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
     int rc = use256 == 2 ? mts_launch_gemm224(a, layout, c_dtype == MTS_F32, splits, st) : mts_launch_gemm256(a, layout, c_dtype == MTS_F32, splits, st);
     if (rc) return rc;
     // (mts_gemm_last_plan: 225 = the 224-wide tile on the four-wave data-gradient kernel of gemm224n.hip -- another symbol in a kernel trace)
-    if (use256 == 2 && (a.variant == 0 || a.variant == 10) && mts_gemm224n_applies(a, layout, c_dtype == MTS_F32, splits)) g_last_tile = 225;
+    if (use256 == 2 && (a.variant == 0 || a.variant == 10 || a.variant == 11) && mts_gemm224n_applies(a, layout, c_dtype == MTS_F32, splits)) g_last_tile = 225;
   } else if (c_dtype == MTS_F32) {
     if (layout == MTS_NT) launch_bf16<MTS_NT, float>(a, splits, st);
     else if (layout == MTS_NN) launch_bf16<MTS_NN, float>(a, splits, st);

@@ -712,7 +712,7 @@ int mts_launch_gemm224n(const GemmArgs& a, int layout, bool c_is_f32, int splits
 int mts_launch_gemm224(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st) {
   // bf16 C, NT (the forward projections): the four-wave kernels with buffer-load LDS-DMA where they apply -- persistent (gemm224p.hip, the default)
   // or one tile per workgroup (gemm224r.hip, gemm_variant 9); bitwise the results of the eight-wave kernel, which gemm_variant 6 keeps (A/B).
-  if (a.variant == 0 && !c_is_f32 && layout == MTS_NT && splits == 1) {
+  if ((a.variant == 0 || a.variant == 11) && !c_is_f32 && layout == MTS_NT && splits == 1) {
     int rc = mts_launch_gemm224p(a, layout, c_is_f32, splits, st);          // persistent form (gemm224p.hip); gemm_variant 9: one tile per workgroup
     if (rc >= 0) return rc;
     GemmArgs b = a;
@@ -720,14 +720,14 @@ int mts_launch_gemm224(const GemmArgs& a, int layout, bool c_is_f32, int splits,
     rc = mts_launch_gemm224r(b, layout, c_is_f32, splits, st);
     if (rc >= 0) return rc;
   }
-  // bf16 C, NN (the data gradients): the four-wave kernel with a k-strided B (gemm224n.hip) where it applies (by default: without a residual;
-  // gemm_variant 10: always); gemm_variant 6 keeps the eight-wave kernel
-  if ((a.variant == 0 || a.variant == 10) && !c_is_f32 && layout == MTS_NN && splits == 1) {
+  // bf16 C, NN (the data gradients): the four-wave kernel with a k-strided B (gemm224n.hip) where it applies (gemm_variant 11: only without a
+  // residual, the round's earlier dispatch); gemm_variant 6 keeps the eight-wave kernel
+  if ((a.variant == 0 || a.variant == 10 || a.variant == 11) && !c_is_f32 && layout == MTS_NN && splits == 1) {
     const int rc = mts_launch_gemm224n(a, layout, c_is_f32, splits, st);
     if (rc >= 0) return rc;
   }
   // fp32 C, TN (the weight gradients): the four-wave unit-pipelined kernel (gemm224t.hip) where it applies; gemm_variant 6 keeps the eight-wave kernel
-  if (a.variant == 0 && c_is_f32 && layout == MTS_TN) {
+  if ((a.variant == 0 || a.variant == 11) && c_is_f32 && layout == MTS_TN) {
     const int rc = mts_launch_gemm224t(a, layout, c_is_f32, splits, st);
     if (rc >= 0) return rc;
   }

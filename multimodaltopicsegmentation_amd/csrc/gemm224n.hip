@@ -20,7 +20,8 @@
 #define N_A_BYTES 32768                       // 256 rows x 128 B (K-major)
 #define N_B_BYTES 32768                       // 2 k-steps x 2 halves x [32 k][256 B]
 #define N_STAGE (N_A_BYTES + N_B_BYTES)
-#define N_LDS (2 * N_STAGE)                   // 128 KiB
+#define N_EPI (2 * N_STAGE)                   // the epilogue's output staging: 4 x 4 KiB behind the stages (the stages take the residual tile)
+#define N_LDS (2 * N_STAGE + 16384)           // 144 KiB
 #define N_BN 224
 #define N_HN 112
 
@@ -154,6 +155,20 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_224n_kernel(const GemmArgs a
   float4 bias[7];
 #pragma unroll
   for (int j = 0; j < 7; ++j) bias[j] = *reinterpret_cast<const float4*>(bias_p + j * 16);
+  // ---- the residual tile goes through the LDS.  Fetched into registers in the epilogue it is 56 loads per lane and a memory round trip per tile
+  // with nothing to hide it (one tile per workgroup): 278 against 246 us on the Q|K|V data gradient.  The two stages are dead a K-tile apart at the
+  // end of the K loop: the wave's rows 0..63 (x 112 columns = 14 chunks of 16 B per row) are copied into the stage of K-tile nk - 2 behind that
+  // K-tile's barrier 2, rows 64..127 into the stage of K-tile nk - 1 behind its last fragment read -- 16 LDS-DMA each, four rows per copy (lane =
+  // (row in four, chunk): 56 of 64 lanes), 16 KiB per wave and half; the epilogue reads 8 bytes per (row, 16-column block) back.
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+      has_res ? (void*)(reinterpret_cast<const bf16_t*>(a.residual) + (size_t)m0 * a.ldr + n0) : (void*)A, 0, 0x7ffffff0, 0x00020000);
+  const unsigned voR = (unsigned)((lane / 14) * a.ldr + (lane % 14) * 8) * 2u;
+  const int rowR4 = 8 * a.ldr;                                     // bytes per 4 rows of the residual
+  // copy c (0..15) of half h: rows 64 h + 4 c .. + 3 -> stage st, 16 KiB of this wave
+  auto res_copy = [&](int c, int h, int st) {
+    if (lane < 56)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsR, (n_dlptr*)(smem + st * N_STAGE + wave_u * 16384 + c * 1024), 16, voR, (h * 16 + c) * rowR4, 0, 0);
+  };
   // ---- prologue: K-tiles 0 and 1 -> stages 0 and 1; the fragments of K-tile 0 / k-step 0 requested ------------------------------------------
   CP16(0, 0);
   CP16(1, 1);
@@ -182,26 +197,35 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_224n_kernel(const GemmArgs a
     lgkm_wait<13>(); NBLOCK(7); NRD(st, 1, 20); NRD(st, 1, 21);                                // (0 + 20) -> 15
     lgkm_wait<0>();                                         // every fragment of this K-tile is in my registers
     if constexpr (ld) __builtin_amdgcn_s_barrier();         // ... and in everybody's: this stage may be overwritten
+    if constexpr (!nxt) { if (has_res) __builtin_amdgcn_s_barrier(); }     // (last K-tile: by the second half of the residual)
 #define KC(c) if constexpr (ld) CP(c, kt + 2, st);
-    NBLOCK(8);  KC(0) KC(1)
-    NBLOCK(9);  KC(2) KC(3)
-    NBLOCK(10); KC(4) KC(5)
-    NBLOCK(11); KC(6) KC(7)
+#define KS0(c0) if constexpr (!nxt) { if (has_res) { res_copy((c0), 1, st); res_copy((c0) + 1, 1, st); } }
+    NBLOCK(8);  KC(0) KC(1) KS0(0)
+    NBLOCK(9);  KC(2) KC(3) KS0(2)
+    NBLOCK(10); KC(4) KC(5) KS0(4)
+    NBLOCK(11); KC(6) KC(7) KS0(6)
+#undef KS0
     if constexpr (nxt) {
       // K-tile kt + 1 (copied during K-tile kt - 1, or in the prologue) has landed: only this K-tile's eight copies may still fly
       if constexpr (ld) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
-    NBLOCK(12); KC(8) KC(9)
+    // K-tile nk - 2 (nxt && !ld): behind barrier 2 nobody reads this stage any more -> the first half of the residual, four copies per block
+    // K-tile nk - 1 (!nxt): the barrier of block 8 below says the same of the last stage -> the second half, two copies per block
+#define KR(c0, n_) if constexpr (nxt && !ld) { if (has_res) { for (int c_ = (c0); c_ < (c0) + (n_); ++c_) res_copy(c_, 0, st); } }
+#define KS(c0) if constexpr (!nxt) { if (has_res) { res_copy((c0), 1, st); res_copy((c0) + 1, 1, st); } }
+    NBLOCK(12); KC(8) KC(9) KR(0, 4) KS(8)
     if constexpr (nxt) { NRD(st ^ 1, 0, 0); NRD(st ^ 1, 0, 1); NRD(st ^ 1, 0, 2); NRD(st ^ 1, 0, 3); NRD(st ^ 1, 0, 4); NRD(st ^ 1, 0, 5); }
-    NBLOCK(13); KC(10) KC(11)
+    NBLOCK(13); KC(10) KC(11) KR(4, 4) KS(10)
     if constexpr (nxt) { lgkm_wait<9>(); NRD(st ^ 1, 0, 6); NRD(st ^ 1, 0, 7); NRD(st ^ 1, 0, 8); NRD(st ^ 1, 0, 9); NRD(st ^ 1, 0, 10); NRD(st ^ 1, 0, 11); }
-    NBLOCK(14); KC(12) KC(13)
+    NBLOCK(14); KC(12) KC(13) KR(8, 4) KS(12)
     if constexpr (nxt) { lgkm_wait<10>(); NRD(st ^ 1, 0, 12); NRD(st ^ 1, 0, 13); NRD(st ^ 1, 0, 14); NRD(st ^ 1, 0, 15); NRD(st ^ 1, 0, 16); }
-    NBLOCK(15); KC(14) KC(15)
+    NBLOCK(15); KC(14) KC(15) KR(12, 4) KS(14)
     if constexpr (nxt) { lgkm_wait<10>(); NRD(st ^ 1, 0, 17); NRD(st ^ 1, 0, 18); NRD(st ^ 1, 0, 19); NRD(st ^ 1, 0, 20); NRD(st ^ 1, 0, 21); }
 #undef KC
+#undef KR
+#undef KS
   };
   {
     using T = std::true_type; using F = std::false_type;
@@ -216,38 +240,37 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_224n_kernel(const GemmArgs a
 #undef NBLOCK
 #undef NRD
 
-  // ---- epilogue (that of gemm_bf16_224d_kernel): bias / column scale / residual, 16 rows at a time through a wave-private LDS area ---------
-  __builtin_amdgcn_s_barrier();
-  char* stage = smem + wave_u * 4096;
-  const size_t res_ld = has_res ? (size_t)a.ldr : 0;
-  const bf16_t* res_p = has_res ? reinterpret_cast<const bf16_t*>(a.residual) + (size_t)(m0 + r16) * a.ldr + n0 + 4 * g
-                                : reinterpret_cast<const bf16_t*>(a.A) + 4 * g;
-  uint2 res[8][7];
-  if (has_res) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 7; ++j) res[i][j] = *reinterpret_cast<const uint2*>(res_p + (size_t)(i * 16) * res_ld + j * 16);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 7; ++j) res[i][j] = make_uint2(0u, 0u);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ---- epilogue: bias / column scale / residual, 16 rows at a time through a wave-private LDS area; the residual out of the stages ------------
+  char* stage = smem + N_EPI + wave_u * 4096;
+  const int stA = (nk - 2) & 1;                              // the stage that took the first half of the residual
+  if (has_res) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // the first half has landed (in-order counter): the second half's 16 copies may still fly
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const float colscale = (a.epi & MTS_EPI_COLSCALE) ? a.colscale : 1.0f;
   const int nsc = (a.epi & MTS_EPI_COLSCALE) ? a.ncols_scaled - n0 - 4 * g : 0;
   bf16_t* __restrict__ C = reinterpret_cast<bf16_t*>(a.C);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
+    // (younger than the second half's copies are the 16 store instructions of groups 0..3)
+    if (i == 4 && has_res) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    uint2 res[7];
+    if (has_res) {
+      // row i * 16 + r16 of the wave's 128 = row (i & 3) * 16 + r16 of its half: copy (row >> 2), lane slot (row & 3) * 14 + chunk
+      const int rr = (i & 3) * 16 + r16;
+      const char* rp = smem + ((i < 4) ? stA : (stA ^ 1)) * N_STAGE + wave_u * 16384 + (rr >> 2) * 1024 + ((rr & 3) * 14 + (g >> 1)) * 16 + (g & 1) * 8;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) res[j] = *reinterpret_cast<const uint2*>(rp + j * 32);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) res[j] = make_uint2(0u, 0u);
+    }
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
       const float sc = (j * 16 < nsc) ? colscale : 1.0f;
       const float4 bb = has_bias ? bias[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-      const uint2 rr = has_res ? res[i][j] : make_uint2(0u, 0u);
+      const uint2 rr2 = has_res ? res[j] : make_uint2(0u, 0u);
       uint2 pk;
-      pk.x = pack_bf16x2((acc[i][j][0] + bb.x) * sc + bf16_lo(rr.x), (acc[i][j][1] + bb.y) * sc + bf16_hi(rr.x));
-      pk.y = pack_bf16x2((acc[i][j][2] + bb.z) * sc + bf16_lo(rr.y), (acc[i][j][3] + bb.w) * sc + bf16_hi(rr.y));
+      pk.x = pack_bf16x2((acc[i][j][0] + bb.x) * sc + bf16_lo(rr2.x), (acc[i][j][1] + bb.y) * sc + bf16_hi(rr2.x));
+      pk.y = pack_bf16x2((acc[i][j][2] + bb.z) * sc + bf16_lo(rr2.y), (acc[i][j][3] + bb.w) * sc + bf16_hi(rr2.y));
       *reinterpret_cast<uint2*>(stage + r16 * 240 + (j * 16 + 4 * g) * 2) = pk;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -265,13 +288,13 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_224n_kernel(const GemmArgs a
 }
 
 // does this kernel take the call?  Measured against the eight-wave kernel at steady state, one process (tools/nn_ab.py, profiles/r04_nn_ab.txt): without a
-// residual 92.0 against 95.3 us (16384 x 1792 x 1792, the attention-output data gradient), 250 against 253 (K = 5376), 747 against 772 (8192 x 7168 x
-// 8192, = the vendor library's 735); WITH a residual 106 against 102 and 278 against 275 -- the eight-wave kernel fetches its 28 residual chunks per
-// lane ahead of the K loop, four waves would need 112 registers for that and fetch them in the epilogue (a memory round trip per tile; touching the
-// rows into L2 seven K-tiles ahead was tried and bought nothing).  So: default only without a residual; gemm_variant 10 forces it for every epilogue.
+// residual 89.8 against 92.6 us (16384 x 1792 x 1792, the attention-output data gradient), 240 against 254 (K = 5376), 725 against 765 (8192 x 7168 x
+// 8192, = the vendor library's 723); with a residual 95.1 against 100.6 and 266 against 271 since the residual tile goes through the LDS stages (fetched
+// into registers in the epilogue -- 56 loads per lane, a memory round trip per tile -- it only tied: 106 / 102, 278 / 275).  gemm_variant 11: the
+// round's earlier dispatch (four waves only where the epilogue has no residual), for the in-step A/B; 6: the eight-wave kernel everywhere.
 bool mts_gemm224n_applies(const GemmArgs& a, int layout, bool c_is_f32, int splits) {
   if (c_is_f32 || splits != 1 || layout != MTS_NN) return false;
-  if ((a.epi & MTS_EPI_RESIDUAL) && a.variant != 10) return false;
+  if ((a.epi & MTS_EPI_RESIDUAL) && a.variant == 11) return false;
   const unsigned simple = MTS_EPI_BIAS | MTS_EPI_COLSCALE | MTS_EPI_RESIDUAL;
   const size_t spanB = ((size_t)a.K + 64) * a.ldb * 2;     // byte offsets of the B copies stay below 2^31
   return !a.slab && (a.epi & ~simple) == 0 && (a.M % 256 == 0) && (a.N % N_BN == 0) && (a.K % BK == 0) && a.K >= 2 * BK && a.ksplit == a.K &&

@@ -193,7 +193,7 @@ def test_gemm_224t_matches_the_eight_wave_kernel_bitwise(ops, M, N, K, splits):
 @pytest.mark.parametrize('M,N,K', [(256, 224, 128), (256, 224, 192), (512, 448, 256), (768, 224, 1088), (512, 1792, 1792), (1024, 1792, 5376)])
 @pytest.mark.parametrize('epi', ['plain', 'residual', 'bias+residual'])
 def test_gemm_224n_matches_the_eight_wave_kernel_bitwise(ops, M, N, K, epi):
-    """Data gradients (NN, bf16 C): the four-wave kernel with a k-strided B (gemm224n.hip; the default without a residual, gemm_variant 10 for every epilogue) against
+    """Data gradients (NN, bf16 C): the four-wave kernel with a k-strided B (gemm224n.hip, the default; the residual tile goes through the LDS stages) against
     the eight-wave kernel (gemm_variant 6) -- same accumulation order per output element, same epilogue arithmetic: identical bits.  Covers the minimum of two
     K-tiles, odd K-tile counts, both step shapes' K, and the residual / bias epilogues; B is a column window of a wider matrix (ldb > N)."""
     from multimodaltopicsegmentation_amd import _lib as L
@@ -205,7 +205,7 @@ def test_gemm_224n_matches_the_eight_wave_kernel_bitwise(ops, M, N, K, epi):
     outs = {}
     try:
         L.check(L.lib.mts_set_option(b'gemm_tile', 224))
-        for variant in (0, 10, 6):            # default (four-wave without a residual) | four-wave for every epilogue | eight-wave
+        for variant in (0, 10, 6):            # default (four-wave) | the same, forced | eight-wave
             L.check(L.lib.mts_set_option(b'gemm_variant', variant))
             o = torch.full((M, N), float('nan'), dtype=torch.bfloat16, device=DEV)
             ops.gemm(L.NN, a, b, o, M=M, N=N, K=K, ldb=N + 224, bias=bias, residual=res)
