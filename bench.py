@@ -513,11 +513,12 @@ def main():
                (0, 224): 'gemm_bf16_224p_kernel<NT,bf16> (256x224, four waves, LDS-DMA, persistent)', (1, 224): 'gemm_bf16_224_kernel<NN,bf16> (256x224)',
                (2, 224): 'gemm_bf16_224t_kernel<TN,f32> (256x224, four waves, LDS-DMA, 32-deep units)',
                (1, 225): 'gemm_bf16_224n_kernel<NN,bf16> (256x224, four waves, LDS-DMA, k-strided B)',
+               (0, 226): 'gemm_bf16_224d_kernel<NT,bf16> (256x224, four waves, LDS-DMA, one tile per workgroup, residual through the LDS)',
                (0, 256): 'gemm_bf16_256_kernel<NT,bf16> (256x256)', (1, 256): 'gemm_bf16_256_kernel<NN,bf16> (256x256)',
                (2, 256): 'gemm_bf16_256_kernel<TN,f32> (256x256)'}
         rocprof_names = {(0, 128): ['void gemm_bf16_kernel<0, bool _Accum, bool, E>(GemmArgs)'], (1, 128): ['void gemm_bf16_kernel<1, bool _Accum, bool, E>(GemmArgs)'],
                          (2, 128): ['void gemm_bf16_kernel<2, float, true>(GemmArgs)'],
-                         (0, 224): ['gemm_bf16_224p_kernel(GemmArgs)', 'gemm_bf16_224d_kernel(GemmArgs)'], (1, 224): ['_Z20gemm_bf16_224_kernelILi1EDF16bLb0ELb1EEv8GemmArgs'],
+                         (0, 224): ['gemm_bf16_224p_kernel(GemmArgs)'], (0, 226): ['gemm_bf16_224d_kernel(GemmArgs)'], (1, 224): ['_Z20gemm_bf16_224_kernelILi1EDF16bLb0ELb1EEv8GemmArgs'],
                          (2, 224): ['void gemm_bf16_224t_kernel<false>(GemmArgs, int, void const*, void const*, float*)', 'gemm_bf16_224t_kernel(GemmArgs, int)'],
                          (1, 225): ['gemm_bf16_224n_kernel(GemmArgs)'],
                          (2, 256): ['void gemm_bf16_256_kernel<2, float, true>(GemmArgs)'],

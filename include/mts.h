@@ -82,7 +82,8 @@ int mts_set_option(const char* key, int value);
  * last poll (mts_last_error() says which).  mts_lstm_fwd / mts_lstm_bwd poll first themselves, so a training loop sees the error
  * at the next step at the latest; a host that has synchronised (decode, checkpoint) calls this.  Reading clears. */
 int mts_async_status(void);
-/* tile width (128 | 224 | 256; 225 = the 224-wide tile on the four-wave data-gradient kernel, a symbol of its own in a kernel trace) and K split the
+/* tile width (128 | 224 | 256; 225 / 226 = the 224-wide tile on the four-wave data-gradient kernel / the one-tile-per-workgroup forward kernel, symbols
+ * of their own in a kernel trace) and K split the
  * cost model chose for the calling thread's most recent bf16 mts_gemm (bench / profiling labels) */
 int mts_gemm_last_plan(int* tile, int* splits);
 /* Measurement aid (per host thread; NULL clears it): fn() is called between the GEMM launch and the split-K reduce launch of every bf16 mts_gemm,

@@ -848,7 +848,7 @@ static void plan_bf16(int c_dtype, int layout, int M, int N, int K, unsigned epi
 }
 
 // ---- two weight gradients of one shape in one launch ------------------------------------------------------------------------------------
-bool mts_gemm224n_applies(const GemmArgs& a, int layout, bool c_is_f32, int splits);   // gemm224n.hip
+int mts_gemm224_last_kernel();   // gemm224.hip
 int mts_launch_gemm224t_pair(const GemmArgs& a, int splits, const void* A2, const void* B2, float* slab2, hipStream_t st);   // gemm224t.hip
 bool mts_gemm224t_applies(const GemmArgs& a, int layout, bool c_is_f32, int splits);
 
@@ -1000,7 +1000,7 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
       a.slab = planes;
       // weight gradients on the 256x224 four-wave kernel: the slice of a tile that arrives last adds the planes inside the launch
       // ("gemm_combine" = 0: the reduce launch, A/B); the kernel's launcher falls back to the eight-wave kernel + reduce launch by itself
-      if (use256 == 2 && g_combine && a.variant == 0 && (size_t)ceil_div(M, 256) * (N / 224) * sizeof(unsigned) <= MTS_GEMM_WS_HEAD &&
+      if (use256 == 2 && g_combine && (a.variant == 0 || a.variant == 11 || a.variant == 12) && (size_t)ceil_div(M, 256) * (N / 224) * sizeof(unsigned) <= MTS_GEMM_WS_HEAD &&
           mts_gemm224t_applies(a, layout, c_dtype == MTS_F32, splits)) {
         a.chain = (unsigned*)workspace;
         chained = true;
@@ -1010,8 +1010,8 @@ extern "C" int mts_gemm(void* stream, int a_dtype, int c_dtype, int layout, int 
   if (use256) {
     int rc = use256 == 2 ? mts_launch_gemm224(a, layout, c_dtype == MTS_F32, splits, st) : mts_launch_gemm256(a, layout, c_dtype == MTS_F32, splits, st);
     if (rc) return rc;
-    // (mts_gemm_last_plan: 225 = the 224-wide tile on the four-wave data-gradient kernel of gemm224n.hip -- another symbol in a kernel trace)
-    if (use256 == 2 && (a.variant == 0 || a.variant == 10 || a.variant == 11) && mts_gemm224n_applies(a, layout, c_dtype == MTS_F32, splits)) g_last_tile = 225;
+    // (mts_gemm_last_plan: 225 / 226 = the 224-wide tile on gemm_bf16_224n_kernel / gemm_bf16_224d_kernel -- other symbols in a kernel trace)
+    if (use256 == 2) g_last_tile = mts_gemm224_last_kernel();
   } else if (c_dtype == MTS_F32) {
     if (layout == MTS_NT) launch_bf16<MTS_NT, float>(a, splits, st);
     else if (layout == MTS_NN) launch_bf16<MTS_NN, float>(a, splits, st);

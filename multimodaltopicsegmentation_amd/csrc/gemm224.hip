@@ -708,32 +708,45 @@ int mts_launch_gemm224t(const GemmArgs& a, int layout, bool c_is_f32, int splits
 int mts_launch_gemm224p(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st);   // gemm224p.hip: four-wave persistent forward (NT) form
 int mts_launch_gemm224n(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st);   // gemm224n.hip: four-wave data-gradient (NN) form
 
+// which kernel the calling thread's last mts_launch_gemm224 ran, as mts_gemm_last_plan reports it: 224, or 225 = gemm_bf16_224n_kernel, 226 =
+// gemm_bf16_224d_kernel (symbols of their own in a kernel trace: per-symbol averages of a bench line and of a rocprofv3 CSV must mean the same launches)
+static thread_local int g_last224 = 224;
+int mts_gemm224_last_kernel() { return g_last224; }
+
 // called from mts_gemm (gemm.hip) when N is a multiple of 224 and the 224-wide tiling fills the CUs better
 int mts_launch_gemm224(const GemmArgs& a, int layout, bool c_is_f32, int splits, hipStream_t st) {
-  // bf16 C, NT (the forward projections): the four-wave kernels with buffer-load LDS-DMA where they apply -- persistent (gemm224p.hip, the default)
-  // or one tile per workgroup (gemm224r.hip, gemm_variant 9); bitwise the results of the eight-wave kernel, which gemm_variant 6 keeps (A/B).
-  if ((a.variant == 0 || a.variant == 11) && !c_is_f32 && layout == MTS_NT && splits == 1) {
-    int rc = mts_launch_gemm224p(a, layout, c_is_f32, splits, st);          // persistent form (gemm224p.hip); gemm_variant 9: one tile per workgroup
-    if (rc >= 0) return rc;
+  g_last224 = 224;
+  // gemm_variant 0 = production.  A/B switches that keep the four-wave kernels: 11 = NN four-wave only where the epilogue has no residual, 12 = NT with a
+  // residual on the persistent kernel (both: the round's earlier dispatch); 10 = NN four-wave forced.  6 = the eight-wave kernels, 9 = NT one tile per workgroup.
+  const bool dflt = a.variant == 0 || a.variant == 11 || a.variant == 12;
+  // bf16 C, NT (the forward projections): the four-wave kernels with buffer-load LDS-DMA where they apply -- persistent (gemm224p.hip), or one tile per
+  // workgroup (gemm224r.hip) where the epilogue has a RESIDUAL: that kernel's stages are free at the end of the K loop and take the residual tile,
+  // the persistent one's are busy with the next tile and it fetches the residual into registers behind a full wait.  Bitwise the eight-wave kernel.
+  if (dflt && !c_is_f32 && layout == MTS_NT && splits == 1) {
     GemmArgs b = a;
     b.variant = 9;
+    if ((a.epi & MTS_EPI_RESIDUAL) && a.variant != 12) {
+      const int rc1 = mts_launch_gemm224r(b, layout, c_is_f32, splits, st);
+      if (rc1 >= 0) { g_last224 = 226; return rc1; }
+    }
+    int rc = mts_launch_gemm224p(a, layout, c_is_f32, splits, st);
+    if (rc >= 0) return rc;
     rc = mts_launch_gemm224r(b, layout, c_is_f32, splits, st);
-    if (rc >= 0) return rc;
+    if (rc >= 0) { g_last224 = 226; return rc; }
   }
-  // bf16 C, NN (the data gradients): the four-wave kernel with a k-strided B (gemm224n.hip) where it applies (gemm_variant 11: only without a
-  // residual, the round's earlier dispatch); gemm_variant 6 keeps the eight-wave kernel
-  if ((a.variant == 0 || a.variant == 10 || a.variant == 11) && !c_is_f32 && layout == MTS_NN && splits == 1) {
+  // bf16 C, NN (the data gradients): the four-wave kernel with a k-strided B (gemm224n.hip) where it applies
+  if ((dflt || a.variant == 10) && !c_is_f32 && layout == MTS_NN && splits == 1) {
     const int rc = mts_launch_gemm224n(a, layout, c_is_f32, splits, st);
-    if (rc >= 0) return rc;
+    if (rc >= 0) { g_last224 = 225; return rc; }
   }
-  // fp32 C, TN (the weight gradients): the four-wave unit-pipelined kernel (gemm224t.hip) where it applies; gemm_variant 6 keeps the eight-wave kernel
-  if ((a.variant == 0 || a.variant == 11) && c_is_f32 && layout == MTS_TN) {
+  // fp32 C, TN (the weight gradients): the four-wave unit-pipelined kernel (gemm224t.hip) where it applies
+  if (dflt && c_is_f32 && layout == MTS_TN) {
     const int rc = mts_launch_gemm224t(a, layout, c_is_f32, splits, st);
     if (rc >= 0) return rc;
   }
   if (a.variant == 9) {                                   // A/B: the one-tile-per-workgroup four-wave kernel where it applies
     const int rc = mts_launch_gemm224r(a, layout, c_is_f32, splits, st);
-    if (rc >= 0) return rc;
+    if (rc >= 0) { g_last224 = 226; return rc; }
   }
   if (c_is_f32) {
     if (layout == MTS_NT) return launch_one<MTS_NT, float>(a, splits, st);

@@ -14,7 +14,8 @@
 #define R_A_BYTES 32768                       // 256 rows x 128 B (K-major)
 #define R_B_BYTES 32768                       // 224 rows x 128 B K-major image (28 KiB used)
 #define R_STAGE (R_A_BYTES + R_B_BYTES)
-#define R_LDS (2 * R_STAGE)                   // 128 KiB
+#define R_EPI (2 * R_STAGE)                   // the epilogue's output staging: 4 x 4 KiB behind the stages (the stages take the residual tile)
+#define R_LDS (2 * R_STAGE + 16384)           // 144 KiB
 #define R_BN 224
 #define R_HN 112
 
@@ -121,6 +122,17 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_224d_kernel(const GemmArgs a
   float4 bias[7];
 #pragma unroll
   for (int j = 0; j < 7; ++j) bias[j] = *reinterpret_cast<const float4*>(bias_p + j * 16);
+  // ---- the residual tile goes through the LDS (as in gemm_bf16_224n_kernel, gemm224n.hip): fetched into registers in the epilogue it is 56 loads per
+  // lane and a memory round trip per tile.  The wave's rows 0..63 (x 14 chunks of 16 B) are copied into the stage of K-tile nk - 2 behind that K-tile's
+  // barrier 2, rows 64..127 into the stage of K-tile nk - 1 behind its last fragment read: 16 LDS-DMA each, four rows per copy (56 of 64 lanes).
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+      has_res ? (void*)(reinterpret_cast<const bf16_t*>(a.residual) + (size_t)m0 * a.ldr + n0) : (void*)A, 0, 0x7ffffff0, 0x00020000);
+  const unsigned voR = (unsigned)((lane / 14) * a.ldr + (lane % 14) * 8) * 2u;
+  const int rowR4 = 8 * a.ldr;                                     // bytes per 4 rows of the residual
+  auto res_copy = [&](int c, int h, int st) {
+    if (lane < 56)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsR, (dlptr_t*)(smem + st * R_STAGE + wave_u * 16384 + c * 1024), 16, voR, (h * 16 + c) * rowR4, 0, 0);
+  };
   // ---- prologue: K-tiles 0 and 1 -> stages 0 and 1; fragments of K-tile 0 / k-step 0 requested -------------------------------------------
   CP(0, 0, 0); CP(1, 0, 0); CP(2, 0, 0); CP(3, 0, 0); CP(4, 0, 0); CP(5, 0, 0); CP(6, 0, 0); CP(7, 0, 0);
   CP(8, 0, 0); CP(9, 0, 0); CP(10, 0, 0); CP(11, 0, 0); CP(12, 0, 0); CP(13, 0, 0); CP(14, 0, 0);
@@ -145,25 +157,32 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_224d_kernel(const GemmArgs a
 #undef KA
     lgkm_wait<0>();                                         // every fragment of this K-tile is in my registers
     if constexpr (ld) __builtin_amdgcn_s_barrier();         // ... and in everybody's: this stage may be overwritten
+    if constexpr (!nxt) { if (has_res) __builtin_amdgcn_s_barrier(); }     // (last K-tile: by the second half of the residual)
 #define KC(c) if constexpr (ld) CP(c, kt + 2, st);
-    VBLOCK(8);  KC(0) KC(1)
-    VBLOCK(9);  KC(2) KC(3)
-    VBLOCK(10); KC(4) KC(5)
-    VBLOCK(11); KC(6) KC(7)
-    VBLOCK(12); KC(8) KC(9)
+    // K-tile nk - 2 (nxt && !ld): behind barrier 2 nobody reads this stage any more -> the first half of the residual (6 + 5 + 5 copies)
+    // K-tile nk - 1 (!nxt): the barrier above says the same of the last stage -> the second half, two copies per block
+#define KR(c0, n_) if constexpr (nxt && !ld) { if (has_res) { for (int c_ = (c0); c_ < (c0) + (n_); ++c_) res_copy(c_, 0, st); } }
+#define KS(c0) if constexpr (!nxt) { if (has_res) { res_copy((c0), 1, st); res_copy((c0) + 1, 1, st); } }
+    VBLOCK(8);  KC(0) KC(1) KS(0)
+    VBLOCK(9);  KC(2) KC(3) KS(2)
+    VBLOCK(10); KC(4) KC(5) KS(4)
+    VBLOCK(11); KC(6) KC(7) KS(6)
+    VBLOCK(12); KC(8) KC(9) KS(8)
     if constexpr (nxt) {
       // K-tile kt + 1 (copied during K-tile kt - 1, or in the prologue) has landed: only this K-tile's ten copies may still fly
       if constexpr (ld) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
-    VBLOCK(13); KC(10) KC(11)
+    VBLOCK(13); KC(10) KC(11) KR(0, 6) KS(10)
     if constexpr (nxt) { VRD(st ^ 1, 0, 0); VRD(st ^ 1, 0, 1); VRD(st ^ 1, 0, 2); VRD(st ^ 1, 0, 3); VRD(st ^ 1, 0, 4); }
-    VBLOCK(14); KC(12) KC(13)
+    VBLOCK(14); KC(12) KC(13) KR(6, 5) KS(12)
     if constexpr (nxt) { VRD(st ^ 1, 0, 5); VRD(st ^ 1, 0, 6); VRD(st ^ 1, 0, 7); VRD(st ^ 1, 0, 8); VRD(st ^ 1, 0, 9); }
-    VBLOCK(15); KC(14)
+    VBLOCK(15); KC(14) KR(11, 5) KS(14)
     if constexpr (nxt) { VRD(st ^ 1, 0, 10); VRD(st ^ 1, 0, 11); VRD(st ^ 1, 0, 12); VRD(st ^ 1, 0, 13); VRD(st ^ 1, 0, 14); }
 #undef KC
+#undef KR
+#undef KS
   };
   {
     using T = std::true_type; using F = std::false_type;
@@ -178,40 +197,36 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_224d_kernel(const GemmArgs a
 #undef VBLOCK
 #undef VRD
 
-  // ---- epilogue ----------------------------------------------------------------------------------------------------------------------------
-  __builtin_amdgcn_s_barrier();
-  char* stage = smem + wave_u * 4096;
-  const size_t res_ld = has_res ? (size_t)a.ldr : 0;
-  const bf16_t* res_p = has_res ? reinterpret_cast<const bf16_t*>(a.residual) + (size_t)(m0 + r16) * a.ldr + n0 + 4 * g
-                                : reinterpret_cast<const bf16_t*>(a.A) + 4 * g;
-  // the bias is wave-uniform work of 7 loads; the residual is 56 loads per lane and a wait of a full memory round trip per tile: only where the
-  // epilogue has one (the forward Q|K|V projection has not: six tiles per CU there)
-  uint2 res[8][7];
-  if (has_res) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 7; ++j) res[i][j] = *reinterpret_cast<const uint2*>(res_p + (size_t)(i * 16) * res_ld + j * 16);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 7; ++j) res[i][j] = make_uint2(0u, 0u);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ---- epilogue: bias / column scale / residual, 16 rows at a time through a wave-private LDS area; the residual out of the stages ------------
+  char* stage = smem + R_EPI + wave_u * 4096;
+  const int stA = (nk - 2) & 1;                              // the stage that took the first half of the residual
+  if (has_res) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // the first half has landed (in-order counter): the second half's 16 copies may still fly
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const float colscale = (a.epi & MTS_EPI_COLSCALE) ? a.colscale : 1.0f;
   const int nsc = (a.epi & MTS_EPI_COLSCALE) ? a.ncols_scaled - n0 - 4 * g : 0;
   bf16_t* __restrict__ C = reinterpret_cast<bf16_t*>(a.C);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
+    // (younger than the second half's copies are the 16 store instructions of groups 0..3)
+    if (i == 4 && has_res) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    uint2 res[7];
+    if (has_res) {
+      const int rr = (i & 3) * 16 + r16;
+      const char* rp = smem + ((i < 4) ? stA : (stA ^ 1)) * R_STAGE + wave_u * 16384 + (rr >> 2) * 1024 + ((rr & 3) * 14 + (g >> 1)) * 16 + (g & 1) * 8;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) res[j] = *reinterpret_cast<const uint2*>(rp + j * 32);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) res[j] = make_uint2(0u, 0u);
+    }
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
       const float sc = (j * 16 < nsc) ? colscale : 1.0f;
       const float4 bb = has_bias ? bias[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-      const uint2 rr = has_res ? res[i][j] : make_uint2(0u, 0u);
+      const uint2 rr2 = has_res ? res[j] : make_uint2(0u, 0u);
       uint2 pk;
-      pk.x = pack_bf16x2((acc[i][j][0] + bb.x) * sc + bf16_lo(rr.x), (acc[i][j][1] + bb.y) * sc + bf16_hi(rr.x));
-      pk.y = pack_bf16x2((acc[i][j][2] + bb.z) * sc + bf16_lo(rr.y), (acc[i][j][3] + bb.w) * sc + bf16_hi(rr.y));
+      pk.x = pack_bf16x2((acc[i][j][0] + bb.x) * sc + bf16_lo(rr2.x), (acc[i][j][1] + bb.y) * sc + bf16_hi(rr2.x));
+      pk.y = pack_bf16x2((acc[i][j][2] + bb.z) * sc + bf16_lo(rr2.y), (acc[i][j][3] + bb.w) * sc + bf16_hi(rr2.y));
       *reinterpret_cast<uint2*>(stage + r16 * 240 + (j * 16 + 4 * g) * 2) = pk;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

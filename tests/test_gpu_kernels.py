@@ -134,7 +134,8 @@ def test_gemm_224_barrier_schedules_agree_bitwise(ops, layout, M, N, K):
     outs = {}
     try:
         L.check(L.lib.mts_set_option(b'gemm_tile', 224))
-        for variant in (0, 5, 6, 9):              # 0: the defaults (NT, bf16 C: the persistent four-wave kernel; else the eight-wave kernel, mid-tile barrier); 5: the eight-wave
+        for variant in (0, 5, 6, 9, 12):          # 0: the defaults (NT, bf16 C: the four-wave kernels -- persistent, or one tile per workgroup with a residual; NN: four-wave); 12: NT with a
+                                                  # residual on the persistent kernel; 5: the eight-wave
                                                   # kernel's end-of-tile barrier schedule; 6: the eight-wave kernel everywhere; 9: the four-wave kernel with one tile per workgroup
             L.check(L.lib.mts_set_option(b'gemm_variant', variant))
             o16 = torch.full((M, N), float('nan'), dtype=torch.bfloat16, device=DEV)
@@ -145,7 +146,7 @@ def test_gemm_224_barrier_schedules_agree_bitwise(ops, layout, M, N, K):
     finally:
         L.check(L.lib.mts_set_option(b'gemm_variant', 0))
         L.check(L.lib.mts_set_option(b'gemm_tile', 0))
-    for v in (5, 6, 9):
+    for v in (5, 6, 9, 12):
         assert torch.equal(outs[0][0].view(torch.int16), outs[v][0].view(torch.int16)), v
         assert torch.equal(outs[0][1].view(torch.int32), outs[v][1].view(torch.int32)), v
     assert not torch.isnan(outs[0][1]).any()
