@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""The fused feed-forward block's weight-gradient shapes (TN, K = 16 384 tokens) on the 128-wide and the 224-wide tile at forced K splits, back to back
+(what mts_wgrad_pair was sized from: one 224-tile launch at 16 slices fills half the chip)."""
 import os, sys, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multimodaltopicsegmentation_amd import _lib as L, ops
 from tools.blas_compare_util import timeit
 dev='cuda'

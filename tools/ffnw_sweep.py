@@ -1,5 +1,5 @@
-import sys, torch
-sys.path.insert(0, '/root/repo')
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multimodaltopicsegmentation_amd import _lib as L, ops
 dev='cuda'
 g=torch.Generator(device=dev).manual_seed(0)
